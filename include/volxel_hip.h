@@ -1,0 +1,208 @@
+/*
+ * volxel_hip.h -- C ABI of libvolxel_hip.so, the MI355X (gfx950) drop-in for the
+ * render boundary of Volxel's volxel-3d-viewer.
+ *
+ * The reference drives its hot path (the per-pixel volume ray loop of
+ * volxel-3d-viewer/src/shaders/fragment.frag) through a set of WebGL2 calls issued by
+ * volxel-3d-viewer/src/viewer.ts.  Every entry point below replaces one group of those
+ * calls; the citation says which.  All paths are relative to the reference repository.
+ *
+ * Conventions
+ *   - plain C, no exceptions, no callbacks; every call returns an int status
+ *     (VX_OK == 0) and vx_last_error() returns the message of the last failure, which
+ *     the host turns into the `throw new Error(...)` of viewer.ts:797-816;
+ *   - one context is used from one thread at a time (the reference is single threaded,
+ *     viewer.ts:1160);
+ *   - host pointers are read synchronously and may be dropped by the caller on return
+ *     (the texImage3D contract of viewer.ts:1106-1142);
+ *   - matrices are 16 floats, column major (gl-matrix / math.gl convention);
+ *   - framebuffers are RGBA32F, row 0 = bottom row (GL origin, vertex.vert:9).
+ */
+#ifndef VOLXEL_HIP_H
+#define VOLXEL_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define VX_OK 0
+#define VX_ERR_INVALID 1      /* bad argument / call order                                */
+#define VX_ERR_DEVICE 2       /* HIP runtime failure (message has hipGetErrorString)      */
+#define VX_ERR_NO_VOLUME 3    /* render before vx_upload_volume (viewer.ts:1081)          */
+#define VX_ERR_NO_DEVICE 4    /* no gfx950 device visible: the product path never falls
+                                 back to a CPU implementation                            */
+
+/* render-mode define of the fragment shader (viewer.ts:66-70,771-787, fragment.frag:3). */
+enum VxRenderMode {
+  VX_MODE_DEFAULT = 0,  /* hierarchical DDA + null collisions   sampling/dda.glsl        */
+  VX_MODE_NO_DDA = 1,   /* delta / ratio tracking               sampling/normal.glsl     */
+  VX_MODE_RAYMARCH = 2, /* 64-step stochastic march             sampling/raymarch.glsl   */
+  VX_MODE_DVR = 3,      /* [build] deterministic front-to-back compositing = E[RAYMARCH],
+                           SURVEY.md section 8 row A12 -- the BASELINE.json headline loop */
+  VX_MODE_DVR_PHONG = 4 /* [build] DVR + central-difference gradient + Phong (config 4)  */
+};
+
+/* device layout of the brick grid used by the trilinear modes */
+enum VxLayout {
+  VX_LAYOUT_REFERENCE = 0, /* the three reference textures, linear buffers (common.glsl:35-43) */
+  VX_LAYOUT_CELLQUAD = 1   /* MI355X native: apron bricks of pre-decoded fp32 xy-quads      */
+};
+
+/*
+ * The uniform block of fragment.frag / utils.glsl / environment.glsl, one POD.
+ * Field-for-field the values viewer.ts:1295-1357 and scene.ts:53-56 bind; the host side
+ * (volxel_amd/renderer.py, js/viewer.js) fills it exactly like bindUniforms() does.
+ * Every member is 4 bytes wide, no padding.
+ */
+typedef struct VxParams {
+  /* utils.glsl:20-21, set at scene.ts:53-56 */
+  float camera_view[16];
+  float camera_proj[16];
+  /* inverse(camera_view) / inverse(camera_proj): the shader inverts per fragment
+     (utils.glsl:24,29,35); hoisted to the host (quirk Q11). */
+  float camera_view_inv[16];
+  float camera_proj_inv[16];
+
+  /* fragment.frag:22, viewer.ts:1319-1320 (already clipped by volumeClipMin/Max) */
+  float volume_aabb_min[3];
+  float volume_aabb_max[3];
+  /* fragment.frag:24-30, viewer.ts:1321-1327 */
+  float volume_min;
+  float volume_maj;
+  float volume_inv_maj;
+  float volume_albedo[3];
+  float volume_phase_g;
+  float volume_density_scale;
+  /* fragment.frag:34-35, viewer.ts:1329-1331 */
+  float density_transform[16];
+  float density_transform_inv[16];
+  /* fragment.frag:43, viewer.ts:1343 */
+  float sample_range[2];
+
+  /* environment.glsl:7-16,  viewer.ts:1303,1338-1340, environment.ts:82-84 */
+  float light_dir[3];
+  float env_strength;
+  int32_t show_environment;
+  int32_t use_env; /* only 0 (directional light) is implemented; env maps are row N3     */
+  int32_t bounces;
+
+  /* fragment.frag:44-51, viewer.ts:1351-1356 */
+  int32_t res[2]; /* u_res; also the render size (quirk Q2 dropped)                       */
+  int32_t debug_hits;
+
+  int32_t render_mode; /* enum VxRenderMode */
+
+  /* [build] parameters of VX_MODE_DVR*; shared verbatim by oracle and kernel            */
+  float dvr_step_voxels; /* march step in index-space voxels (BASELINE config: 0.5)      */
+  float dvr_ert_tau;     /* early ray termination once optical depth tau >= this
+                            (= -ln(eps) for a transmittance threshold eps)               */
+  int32_t dvr_jitter;    /* 1: sub-pixel + start jitter from the RNG like the reference
+                            (fragment.frag:146, raymarch.glsl:330); 0: pixel centre,
+                            start offset 0.5 step                                        */
+  int32_t dvr_max_steps;
+  float dvr_gain[3];     /* albedo * mis * f_p * Le / pdf  (fragment.frag:94-97), host-computed */
+  /* Phong terms of VX_MODE_DVR_PHONG */
+  float phong_ka, phong_kd, phong_ks, phong_shininess;
+
+  /* image-space sharding: this context renders the tiles
+     t with t % shard_count == shard_rank, tile = shard_tile x shard_tile pixels        */
+  int32_t shard_rank;
+  int32_t shard_count;
+} VxParams;
+
+/* exact work counters of the launches since the last vx_reset_counters */
+typedef struct VxCounters {
+  uint64_t samples;      /* volume sample evaluations (density lookup + TF + accumulate)  */
+  uint64_t rays;         /* primary rays that hit the clipped AABB                        */
+  uint64_t pixels;       /* pixels written                                                */
+  uint64_t skip_steps;   /* DDA / empty-space steps (not samples)                         */
+  uint64_t grad_samples; /* samples that also evaluated the 6-tap gradient (DVR_PHONG)    */
+  uint64_t launches;     /* render-kernel launches                                        */
+  double kernel_ms;      /* sum of HIP-event durations of those launches                  */
+  double last_kernel_ms; /* duration of the most recent launch                            */
+} VxCounters;
+
+typedef struct VxContext VxContext;
+
+#define VX_SHARD_TILE 64 /* pixels per side of one sharding tile */
+
+/* ---- lifecycle: replaces canvas.getContext("webgl2") + program/FBO/texture creation
+ *      (viewer.ts:221-414).  device_id = HIP ordinal.  Fails with VX_ERR_NO_DEVICE
+ *      when no GPU is present.  */
+int vx_create(int device_id, VxContext** out_ctx);
+void vx_destroy(VxContext* ctx);
+/* message of the last failed call on ctx (ctx may be NULL for vx_create failures) */
+const char* vx_last_error(const VxContext* ctx);
+
+/* run all work of this context on an existing HIP stream (hipStream_t passed as void*);
+ * NULL = the context's own stream.  Lets a torch/RCCL host order copies and collectives. */
+int vx_set_stream(VxContext* ctx, void* hip_stream);
+
+/* ---- volume upload: replaces setupFromGrid's four texImage3D groups
+ *      (viewer.ts:1106-1142); arguments are field-for-field WasmWorkerMessageDicomReturn
+ *      (common.ts:37-55).  `range` and the mips are the LE u16 stream [max,min] per brick
+ *      (brick.rs:19-23,357-359).  n_mips must be 3 (brick.rs:13).  */
+int vx_upload_volume(VxContext* ctx,
+                     const uint32_t* indirection, const uint32_t indirection_size[3],
+                     const uint16_t* range, const uint32_t range_size[3],
+                     const uint8_t* atlas, const uint32_t atlas_size[3],
+                     int n_mips, const uint16_t* const* mip_data, const uint32_t (*mip_size)[3],
+                     const uint32_t index_extent[3]);
+
+/* select the device layout the trilinear modes sample from (default VX_LAYOUT_CELLQUAD);
+ * takes effect at the next vx_upload_volume or immediately if a volume is resident. */
+int vx_set_layout(VxContext* ctx, int layout);
+
+/* ---- transfer function: replaces changeTransferFunc's texImage2D (viewer.ts:1147-1153);
+ *      rgba = length x 4 floats, sampled NEAREST + CLAMP_TO_EDGE (viewer.ts:386-389). */
+int vx_upload_transfer(VxContext* ctx, const float* rgba, uint32_t length);
+
+/* ---- uniforms: replaces bindUniforms + Camera.bindAsUniforms (viewer.ts:1295-1357,
+ *      scene.ts:53-56). */
+int vx_set_params(VxContext* ctx, const VxParams* params);
+
+/* ---- framebuffers: replaces resizeFramebuffersToCanvas / the two RGBA32F ping-pong
+ *      FBOs (viewer.ts:294-324).  Clears the accumulation. */
+int vx_resize(VxContext* ctx, uint32_t width, uint32_t height);
+
+/* ---- one accumulation sample: replaces gl.drawArrays(TRIANGLE_STRIP,0,4) of the
+ *      path-tracing program (viewer.ts:1208-1211) including the running-mean blend
+ *      out = w*prev + (1-w)*result (fragment.frag:158); frame_index = u_frame_index,
+ *      sample_weight = u_sample_weight (viewer.ts:1351,1356).  Asynchronous on the
+ *      context's stream. */
+int vx_render_frame(VxContext* ctx, uint32_t frame_index, float sample_weight);
+
+/* ---- synchronise: replaces gl.finish() (viewer.ts:1214,1289) */
+int vx_finish(VxContext* ctx);
+
+/* ---- readback of the accumulation buffer (what blit.frag samples as u_result),
+ *      width*height*4 floats, row 0 = bottom.  Synchronises. */
+int vx_read_accum(VxContext* ctx, float* rgba_out);
+/* ---- display pass: replaces the blit program (blit.frag:17-35, viewer.ts:1259-1265):
+ *      Hable tonemap + gamma, RGBA8, width*height*4 bytes.  Synchronises. */
+int vx_read_display(VxContext* ctx, uint8_t* rgba8_out, float exposure, float gamma);
+
+/* device-side views for a zero-copy host (torch / RCCL gather): the tile-major slab this
+ * shard owns (floats = vx_slab_floats) and a de-tiling pass from a gathered set of slabs. */
+int vx_slab_info(VxContext* ctx, uint64_t* slab_floats, uint32_t* tiles_per_shard);
+int vx_slab_device_ptr(VxContext* ctx, void** dev_ptr);
+/* gathered = shard_count slabs back to back (device pointer); writes row-major W*H*4 floats
+ * to image_out (device pointer). */
+int vx_detile(VxContext* ctx, const void* gathered_dev, void* image_out_dev);
+
+/* ---- counters: the benchmark harness of viewer.ts:1213-1252 measures wall time around
+ *      gl.finish(); here the kernel is bracketed by HIP events on its own stream. */
+int vx_get_counters(VxContext* ctx, VxCounters* out);
+int vx_reset_counters(VxContext* ctx);
+
+/* library / device facts for logs (viewer.ts:225-242 device record) */
+int vx_device_info(VxContext* ctx, char* name_out, uint32_t name_cap, uint32_t* cu_count,
+                   uint64_t* hbm_bytes);
+const char* vx_version(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* VOLXEL_HIP_H */

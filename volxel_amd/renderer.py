@@ -1,0 +1,309 @@
+"""Host-side mirror of the reference's render core (volxel-3d-viewer/src/viewer.ts) above
+the C ABI of libvolxel_hip.so.
+
+`Volxel3DRenderer` keeps the names of the reference class `Volxel3DDicomRenderer`
+(viewer.ts:111) for the calls on the hot path:
+
+    setup_from_grid(grid)          viewer.ts:1080-1145   (setupFromGrid)
+    change_transfer_func(data, n)  viewer.ts:1147-1153   (changeTransferFunc)
+    restart_rendering()            viewer.ts:1155-1181   (frameIndex = 0)
+    bind_uniforms()                viewer.ts:1295-1357   (+ scene.ts:53-56)
+    render()                       viewer.ts:1183-1293   (one accumulation sample)
+    restore_settings(json)         viewer.ts:704-713
+    render_mode (property)         viewer.ts:1442-1452
+
+Everything that touches pixels goes through the HIP library; there is no CPU fallback.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import math
+
+import numpy as np
+
+from . import _abi
+from .scene import Camera, Grid, Volume, flat, from_flat
+from .settings import ViewerSettings, verify_settings
+from .transfer import default_transfer_function, generate_transfer_function
+
+LOW_RESOLUTION_DURATION = 5  # viewer.ts:132
+
+
+class VolxelError(RuntimeError):
+    """What viewer.ts:797-816 handleError receives."""
+
+
+def sample_weight(frame_index: int, low_res_duration: int = LOW_RESOLUTION_DURATION) -> float:
+    """viewer.ts:1356."""
+    if frame_index < low_res_duration:
+        return 0.0
+    return (frame_index - low_res_duration) / (frame_index - low_res_duration + 1)
+
+
+def compute_params(settings: ViewerSettings, camera: Camera, volume: Volume, density_scale: float,
+                   width: int, height: int, env_strength: float = 1.0, shard_rank: int = 0,
+                   shard_count: int = 1) -> "_abi.VxParams":
+    """bindUniforms (viewer.ts:1295-1357) + Camera.bindAsUniforms (scene.ts:53-56):
+    doubles on the host, rounded to float32 on upload."""
+    p = _abi.VxParams()
+
+    def put(name, arr):
+        a = np.asarray(arr, dtype=np.float64).astype(np.float32).reshape(-1)
+        getattr(p, name)[:] = a.tolist()
+
+    view = camera.view_matrix()
+    proj = camera.proj_matrix(width / height)
+    view32 = from_flat(flat(view).astype(np.float32))  # the shader only sees the f32 upload
+    proj32 = from_flat(flat(proj).astype(np.float32))
+    put("camera_view", flat(view))
+    put("camera_proj", flat(proj))
+    put("camera_view_inv", flat(np.linalg.inv(view32)))   # inverse(camera_view), utils.glsl:24
+    put("camera_proj_inv", flat(np.linalg.inv(proj32)))   # inverse(camera_proj), utils.glsl:29
+
+    mn, maj = volume.min_maj()
+    lo, hi = volume.aabb_clipped(settings.volume_clip_min, settings.volume_clip_max)
+    put("volume_aabb_min", lo)
+    put("volume_aabb_max", hi)
+    mult = settings.density_multiplier
+    p.volume_min = mn * density_scale * mult                 # viewer.ts:1321
+    p.volume_maj = maj * density_scale * mult                # viewer.ts:1322
+    p.volume_inv_maj = 1.0 / (maj * density_scale * mult)    # viewer.ts:1323
+    put("volume_albedo", [0.9, 0.9, 0.9])                    # viewer.ts:1325
+    p.volume_phase_g = 0.0                                   # viewer.ts:1326
+    p.volume_density_scale = density_scale * mult            # viewer.ts:1327
+    combined = volume.combined_transform()
+    put("density_transform", flat(combined))                 # viewer.ts:1330
+    put("density_transform_inv", flat(np.linalg.inv(combined)))  # viewer.ts:1331
+    put("sample_range", settings.sample_range)               # viewer.ts:1343
+
+    put("light_dir", settings.light_dir)                     # viewer.ts:1303
+    p.env_strength = env_strength                            # environment.ts:83
+    p.show_environment = 1 if settings.show_environment else 0   # viewer.ts:1338
+    p.use_env = 0   # env-map lighting is SURVEY row N3; the directional branch is implemented
+    p.bounces = int(settings.bounces)                        # viewer.ts:1339
+    p.res[0], p.res[1] = int(width), int(height)             # viewer.ts:1353 (quirk Q2 dropped)
+    p.debug_hits = 1 if settings.debug_hits else 0           # viewer.ts:1354
+    p.render_mode = _abi.RENDER_MODES[settings.render_mode]
+
+    p.dvr_step_voxels = settings.dvr_step_voxels
+    p.dvr_ert_tau = -math.log(settings.dvr_ert_epsilon)
+    p.dvr_jitter = 1 if settings.dvr_jitter else 0
+    p.dvr_max_steps = int(settings.dvr_max_steps)
+    # K = albedo * mis * f_p * Le / pdf for the directional light (fragment.frag:94-97,
+    # environment.glsl:30-33, utils.glsl:104,121-124), in float32 like the shader
+    f32 = np.float32
+    inv_4pi = f32(1.0) / (f32(4.0) * f32(math.pi))
+    f_p = inv_4pi * (f32(1.0) - f32(0.0)) / (f32(1.0) * f32(1.0))
+    mis = (f32(1.0) / (f32(1.0) + f_p * f_p)) if settings.show_environment else f32(1.0)
+    le = f32(env_strength) * f32(4.01)
+    gain = ((f32(0.9) * mis) * f_p) * le
+    put("dvr_gain", [gain, gain, gain])
+    p.phong_ka, p.phong_kd, p.phong_ks, p.phong_shininess = [float(x) for x in settings.phong]
+    p.shard_rank, p.shard_count = int(shard_rank), int(shard_count)
+    return p
+
+
+class Volxel3DRenderer:
+    """Headless counterpart of the `<volxel-3d-viewer>` element's render core."""
+
+    def __init__(self, width: int = 1920, height: int = 1080, device: int = 0,
+                 shard_rank: int = 0, shard_count: int = 1, layout: int | None = None):
+        self._lib = _abi.load_library()
+        self._ctx = C.c_void_p()
+        rc = self._lib.vx_create(int(device), C.byref(self._ctx))
+        if rc != 0:
+            msg = self._lib.vx_last_error(None)
+            self._ctx = None
+            raise VolxelError(msg.decode() if msg else f"vx_create failed ({rc})")
+        self.settings = ViewerSettings()
+        self.camera = Camera(1)                       # viewer.ts:418
+        self.volume: Volume | None = None
+        self.density_scale = 1.0
+        self.env_strength = 1.0
+        self.frame_index = 0
+        self.width, self.height = int(width), int(height)
+        self.shard_rank, self.shard_count = shard_rank, shard_count
+        self.low_resolution_duration = LOW_RESOLUTION_DURATION
+        if layout is not None:
+            self._check(self._lib.vx_set_layout(self._ctx, int(layout)))
+        self._check(self._lib.vx_resize(self._ctx, self.width, self.height))
+        data, length = default_transfer_function()    # viewer.ts:377-385
+        self.change_transfer_func(data, length)
+
+    # -- error contract (viewer.ts:797-816) -------------------------------------------
+    def _check(self, rc):
+        if rc != 0:
+            raise VolxelError(self._lib.vx_last_error(self._ctx).decode())
+
+    def close(self):
+        if getattr(self, "_ctx", None):
+            self._lib.vx_destroy(self._ctx)
+            self._ctx = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    # -- viewer.ts:1442-1452 ------------------------------------------------------------
+    @property
+    def render_mode(self) -> str:
+        return self.settings.render_mode
+
+    @render_mode.setter
+    def render_mode(self, to: str):
+        if to not in _abi.RENDER_MODES:
+            raise VolxelError(f"Unrecognized render mode provided: {to}")
+        self.settings.render_mode = to
+        self.restart_rendering()
+
+    # -- viewer.ts:1080-1145 ------------------------------------------------------------
+    def setup_from_grid(self, grid):
+        """grid: preprocessor.BrickGridMessage (= WasmWorkerMessageDicomReturn)."""
+        self.density_scale = 1.0
+        self.settings.volume_clip_max = (1.0, 1.0, 1.0)
+        self.settings.volume_clip_min = (0.0, 0.0, 0.0)
+        g = Grid(min_maj=tuple(grid.min_maj), index_extent=np.asarray(grid.index_extent, float),
+                 transform=from_flat(grid.transform))
+        self.volume = Volume(g)
+        self.density_scale *= self.volume.normalise()
+        u3 = lambda t: (C.c_uint32 * 3)(*[int(x) for x in t])
+        ind = np.ascontiguousarray(grid.indirection, dtype=np.uint32)
+        rng = np.ascontiguousarray(grid.range, dtype=np.uint16)
+        atl = np.ascontiguousarray(grid.atlas, dtype=np.uint8)
+        n = len(grid.range_mipmaps)
+        mips = [np.ascontiguousarray(m, dtype=np.uint16) for m, _ in grid.range_mipmaps]
+        mip_ptrs = (C.c_void_p * max(n, 1))(*[m.ctypes.data for m in mips])
+        mip_sizes = (C.c_uint32 * (3 * max(n, 1)))(*[int(x) for _, s in grid.range_mipmaps for x in s])
+        self._check(self._lib.vx_upload_volume(
+            self._ctx, ind.ctypes.data, u3(grid.indirection_size), rng.ctypes.data,
+            u3(grid.range_size), atl.ctypes.data if atl.size else None, u3(grid.atlas_size), n,
+            mip_ptrs, C.cast(mip_sizes, C.c_void_p), u3(grid.index_extent)))
+        self.restart_rendering()
+
+    # -- viewer.ts:1147-1153 ------------------------------------------------------------
+    def change_transfer_func(self, data, length: int):
+        a = np.ascontiguousarray(data, dtype=np.float32).reshape(-1)
+        if a.size != 4 * length:
+            raise VolxelError("transfer function must hold length*4 floats")
+        self._check(self._lib.vx_upload_transfer(self._ctx, a.ctypes.data, int(length)))
+        self._tf = (a.copy(), int(length))
+        self.frame_index = 0
+
+    def set_color_stops(self, colors, steps: int = 128):
+        data, length = generate_transfer_function(colors, steps)
+        self.change_transfer_func(data, length)
+
+    # -- viewer.ts:1155-1181 ------------------------------------------------------------
+    def restart_rendering(self):
+        self.frame_index = 0
+
+    def resize(self, width: int, height: int):
+        self.width, self.height = int(width), int(height)
+        self._check(self._lib.vx_resize(self._ctx, self.width, self.height))
+        self.restart_rendering()
+
+    # -- viewer.ts:704-713 restoreSettings ---------------------------------------------
+    def restore_settings(self, s: dict):
+        verify_settings(s)
+        t = s["transfer"]
+        self.settings.density_multiplier = t["densityMultiplier"]
+        self.settings.sample_range = tuple(t["histogramRange"])          # viewer.ts:650
+        if t["transfer"]["type"] == "color_stops":
+            self.set_color_stops(t["transfer"]["colors"])
+        else:
+            rows = np.asarray(t["transfer"]["colors"], dtype=np.float32)
+            self.change_transfer_func(rows.reshape(-1), rows.shape[0])
+        d = s["display"]
+        self.settings.bounces = d["bounces"]
+        self.settings.max_samples = d["samples"]
+        self.settings.gamma, self.settings.exposure = d["gamma"], d["exposure"]
+        self.settings.debug_hits = d["debugHits"]
+        self.settings.render_mode = d["renderMode"]
+        self.settings.resolution_factor = d["resolutionFactor"]
+        l = s["lighting"]
+        self.settings.show_environment = l["showEnv"]
+        self.settings.use_env = l["useEnv"]
+        self.env_strength = l["envStrength"]
+        self.settings.sync_light_dir = l["syncLightDir"]
+        self.settings.light_dir = tuple(l["lightDir"])
+        o = s["other"]
+        self.settings.volume_clip_max = tuple(o["clipMax"])
+        self.settings.volume_clip_min = tuple(o["clipMin"])
+        self.camera.pos = np.asarray(o["cameraPos"], dtype=np.float64)
+        self.camera.view = np.asarray(o["cameraLookAt"], dtype=np.float64)
+        self.restart_rendering()
+
+    # -- viewer.ts:1295-1357 ------------------------------------------------------------
+    def bind_uniforms(self):
+        if self.volume is None:
+            raise VolxelError("Trying to bind uniforms without a volume.")
+        p = compute_params(self.settings, self.camera, self.volume, self.density_scale, self.width,
+                           self.height, self.env_strength, self.shard_rank, self.shard_count)
+        self._check(self._lib.vx_set_params(self._ctx, C.byref(p)))
+        self._params = p
+        return p
+
+    # -- viewer.ts:1183-1293 ------------------------------------------------------------
+    def render(self, frames: int = 1, rebind: bool = True):
+        """Render `frames` accumulation samples (the body of render() while
+        frameIndex <= maxSamples).  Asynchronous; call finish() or a read_* to wait."""
+        if rebind:
+            self.bind_uniforms()
+        for _ in range(frames):
+            if self.frame_index > self.settings.max_samples:     # viewer.ts:1194
+                break
+            w = sample_weight(self.frame_index, self.low_resolution_duration)
+            self._check(self._lib.vx_render_frame(self._ctx, self.frame_index, w))
+            self.frame_index += 1
+
+    def finish(self):  # gl.finish(), viewer.ts:1289
+        self._check(self._lib.vx_finish(self._ctx))
+
+    def read_accum(self) -> np.ndarray:
+        out = np.empty((self.height, self.width, 4), dtype=np.float32)
+        self._check(self._lib.vx_read_accum(self._ctx, out.ctypes.data))
+        return out
+
+    def read_display(self) -> np.ndarray:  # blit pass, viewer.ts:1259-1265
+        out = np.empty((self.height, self.width, 4), dtype=np.uint8)
+        self._check(self._lib.vx_read_display(self._ctx, out.ctypes.data,
+                                              float(self.settings.exposure), float(self.settings.gamma)))
+        return out
+
+    # -- measurement hooks (viewer.ts:1213-1252 benchmark harness) -----------------------
+    def counters(self):
+        c = _abi.VxCounters()
+        self._check(self._lib.vx_get_counters(self._ctx, C.byref(c)))
+        return c
+
+    def reset_counters(self):
+        self._check(self._lib.vx_reset_counters(self._ctx))
+
+    def set_stream(self, hip_stream: int | None):
+        self._check(self._lib.vx_set_stream(self._ctx, C.c_void_p(hip_stream or 0)))
+
+    def set_layout(self, layout: int):
+        self._check(self._lib.vx_set_layout(self._ctx, int(layout)))
+
+    def device_info(self):
+        name = C.create_string_buffer(256)
+        cus, mem = C.c_uint32(), C.c_uint64()
+        self._check(self._lib.vx_device_info(self._ctx, name, 256, C.byref(cus), C.byref(mem)))
+        return name.value.decode(), cus.value, mem.value
+
+    # -- zero-copy slab access for the RCCL gather (volxel_amd/dist.py) -----------------
+    def slab_info(self):
+        n, t = C.c_uint64(), C.c_uint32()
+        self._check(self._lib.vx_slab_info(self._ctx, C.byref(n), C.byref(t)))
+        return n.value, t.value
+
+    def slab_device_ptr(self) -> int:
+        p = C.c_void_p()
+        self._check(self._lib.vx_slab_device_ptr(self._ctx, C.byref(p)))
+        return p.value
+
+    def detile(self, gathered_dev_ptr: int, image_dev_ptr: int):
+        self._check(self._lib.vx_detile(self._ctx, C.c_void_p(gathered_dev_ptr),
+                                        C.c_void_p(image_dev_ptr)))

@@ -1,0 +1,137 @@
+"""Host-side scene math, mirroring volxel-3d-viewer/src/representation/{scene,volume,grid}.ts.
+
+The reference does this in JavaScript doubles through math.gl 4.1.0 (a gl-matrix wrapper,
+not vendored in the reference: parity unpinned) and uploads float32 uniforms.  Here: numpy
+float64, column-major 4x4 stored as arrays m[col, row] flattened like gl-matrix
+(flat[4*col + row]).
+"""
+from __future__ import annotations
+
+import math
+from dataclasses import dataclass, field
+
+import numpy as np
+
+
+def mat4_identity():
+    return np.eye(4, dtype=np.float64)
+
+
+# Matrices are kept as "math" matrices M[row, col]; flat() converts to gl-matrix order.
+def flat(m) -> np.ndarray:
+    return np.asarray(m, dtype=np.float64).T.reshape(16).copy()
+
+
+def from_flat(a) -> np.ndarray:
+    return np.asarray(a, dtype=np.float64).reshape(4, 4).T.copy()
+
+
+def look_at(eye, center, up) -> np.ndarray:
+    """gl-matrix mat4.lookAt as used by scene.ts:58-64."""
+    eye = np.asarray(eye, dtype=np.float64)
+    center = np.asarray(center, dtype=np.float64)
+    up = np.asarray(up, dtype=np.float64)
+    if np.all(np.abs(eye - center) < 1e-6):
+        return mat4_identity()
+    z = eye - center
+    z = z / math.sqrt(float(z @ z))
+    x = np.cross(up, z)
+    lx = math.sqrt(float(x @ x))
+    x = x / lx if lx else np.zeros(3)
+    y = np.cross(z, x)
+    ly = math.sqrt(float(y @ y))
+    y = y / ly if ly else np.zeros(3)
+    m = mat4_identity()
+    m[0, :3], m[1, :3], m[2, :3] = x, y, z
+    m[0, 3], m[1, 3], m[2, 3] = -(x @ eye), -(y @ eye), -(z @ eye)
+    return m
+
+
+def perspective(fovy, aspect, near, far) -> np.ndarray:
+    """gl-matrix mat4.perspective (OpenGL clip z in [-1,1]), scene.ts:65-72."""
+    f = 1.0 / math.tan(fovy / 2.0)
+    nf = 1.0 / (near - far)
+    m = np.zeros((4, 4), dtype=np.float64)
+    m[0, 0] = f / aspect
+    m[1, 1] = f
+    m[2, 2] = (far + near) * nf
+    m[3, 2] = -1.0
+    m[2, 3] = 2.0 * far * near * nf
+    return m
+
+
+def scale_m(s) -> np.ndarray:
+    m = mat4_identity()
+    s = np.broadcast_to(np.asarray(s, dtype=np.float64), (3,))
+    m[0, 0], m[1, 1], m[2, 2] = s
+    return m
+
+
+def translate_m(v) -> np.ndarray:
+    m = mat4_identity()
+    m[:3, 3] = np.asarray(v, dtype=np.float64)
+    return m
+
+
+class Camera:
+    """scene.ts:3-72 (orbit controls omitted: input handling is out of scope)."""
+
+    up = np.array([0.0, 1.0, 0.0])
+
+    def __init__(self, distance: float = 1.0):
+        self.view = np.zeros(3)                       # look-at point (scene.ts:11)
+        self.pos = np.array([0.0, 0.0, -distance])    # scene.ts:12
+
+    def view_matrix(self) -> np.ndarray:
+        return look_at(self.pos, self.view, Camera.up)
+
+    def proj_matrix(self, aspect: float, fov: float = math.pi / 3) -> np.ndarray:
+        return perspective(fov, aspect, 0.1, 1000.0)
+
+
+@dataclass
+class Grid:
+    """representation/grid.ts:4-13 -- the host-side facts of an uploaded brick grid."""
+    min_maj: tuple
+    index_extent: np.ndarray
+    transform: np.ndarray  # math matrix (row, col)
+
+
+class Volume:
+    """representation/volume.ts:5-48."""
+
+    def __init__(self, grid: Grid):
+        self.grid = grid
+        self.transform = mat4_identity()
+
+    def combined_transform(self) -> np.ndarray:     # volume.ts:14-16
+        return self.transform @ self.grid.transform
+
+    def to_world(self, index4) -> np.ndarray:       # volume.ts:17-20
+        return self.combined_transform() @ np.asarray(index4, dtype=np.float64)
+
+    def aabb(self):                                 # volume.ts:25-31
+        lo = self.to_world([0, 0, 0, 1])
+        e = self.grid.index_extent
+        hi = self.to_world([e[0], e[1], e[2], 1])
+        return lo[:3].copy(), hi[:3].copy()
+
+    def aabb_clipped(self, cmin, cmax):             # volume.ts:32-37
+        lo, hi = self.aabb()
+        cmin = np.asarray(cmin, dtype=np.float64)
+        cmax = np.asarray(cmax, dtype=np.float64)
+        return lo + (hi - lo) * cmin, lo + (hi - lo) * cmax
+
+    def min_maj(self):
+        return self.grid.min_maj
+
+    def normalise(self) -> float:
+        """viewer.ts:1086-1099: centre at the origin, longest side 1; returns densityScale."""
+        lo, hi = self.aabb()
+        extent = hi - lo
+        size = float(max(extent[0], max(extent[1], extent[2])))
+        density_scale = 1.0
+        if size != 1:
+            self.transform = scale_m(1.0 / size) @ translate_m(-lo - extent * 0.5)
+            density_scale *= size
+        return density_scale
