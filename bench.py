@@ -1,0 +1,204 @@
+#!/usr/bin/env python3
+"""bench.py -- headline benchmark: Gsamples/s of the DVR raymarch on BASELINE config 3
+(512^3 volume, 1920x1080, trilinear + 1-D TF LUT, early ray termination, clip box).
+
+    python bench.py --gpus 1 --steps K --warmup W
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
+
+A "step" is one accumulation frame (one pass of the hot path over every pixel).  With N > 1
+the frame's 64x64 tiles are dealt round-robin to the ranks (volume replicated, no collective
+in the data path) and the framebuffer is all_gathered over RCCL once per frame
+(strong scaling: the frame is fixed, `value` = samples of all ranks / max-over-ranks time).
+
+Prints ONE JSON line on rank 0 (contract in the task statement), with
+  roofline     achieved algorithmic bytes (16 B/sample + 32 B/pixel) per launch /
+               average HIP-event kernel duration, against the 8 TB/s HBM peak;
+  cpu_baseline the scalar CPU oracle (oracle/, kind "port") timed on this box's host cores on a
+               centred 480x270 crop of the same frame.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0      # MI355X_MICROARCH.md: HBM3E peak 8.0 TB/s (spec)
+BYTES_PER_SAMPLE = 16.0    # 8 x 1 B voxels + 4 B range + 4 B indirection
+BYTES_PER_PIXEL = 32.0     # RGBA32F accumulator read + write
+
+
+def build_scene(width, height, n_vox, rank, world, device):
+    from volxel_amd import (BENCHMARK_SETTINGS, Volxel3DRenderer, read_u16_stack_to_grid, synth)
+    t0 = time.time()
+    vox, sp = synth.value_noise(n_vox, seed=42)
+    t1 = time.time()
+    msg = read_u16_stack_to_grid(vox, sp)
+    t2 = time.time()
+    del vox
+    r = Volxel3DRenderer(width, height, device=device, shard_rank=rank, shard_count=world)
+    r.setup_from_grid(msg)
+    r.restore_settings(BENCHMARK_SETTINGS)      # TF stops, camera pose, histogram range, multiplier
+    r.settings.render_mode = "dvr"
+    r.settings.volume_clip_min = (0.25, 0.0, 0.0)
+    r.settings.volume_clip_max = (1.0, 1.0, 0.75)
+    r.settings.dvr_step_voxels = 0.5
+    r.settings.dvr_ert_epsilon = 1e-4
+    r.settings.max_samples = 1 << 30
+    t3 = time.time()
+    nb = int(np.prod(msg.indirection_size))
+    info = dict(gen_s=round(t1 - t0, 2), brick_build_s=round(t2 - t1, 2), upload_s=round(t3 - t2, 2),
+                bricks=nb, nonconstant_bricks=int(msg.brick_counter))
+    return r, msg, info
+
+
+def cpu_baseline(r, msg, crop=(480, 270)):
+    """scalar CPU port (the parity oracle) on a centred crop of the same frame"""
+    from oracle import oracle as O
+    p = r.bind_uniforms()
+    W, H = r.width, r.height
+    x0, y0 = (W - crop[0]) // 2, (H - crop[1]) // 2
+    tf, L = r._tf
+    threads = os.cpu_count() or 1
+    vol = O.make_volume(msg)
+    t0 = time.perf_counter()
+    _, c = O.render(p, vol, tf, L, frame_index=0, rect=(x0, x0 + crop[0], y0, y0 + crop[1]), threads=threads)
+    dt = time.perf_counter() - t0
+    return {"value": round(c.samples / dt / 1e9, 5), "unit": "Gsamples/s", "cores": threads, "kind": "port",
+            "sample": f"centred {crop[0]}x{crop[1]} crop of the same frame, {c.samples} samples in {dt:.2f} s "
+                      f"({threads} threads over row bands)",
+            "ms_per_frame_crop": round(dt * 1e3, 1)}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=60)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--width", type=int, default=1920)
+    ap.add_argument("--height", type=int, default=1080)
+    ap.add_argument("--volume", type=int, default=512)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--layout", type=int, default=None, help="0 reference, 1 cellquad (default)")
+    a = ap.parse_args()
+
+    import torch
+    import torch.distributed as dist
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != a.gpus and world > 1:
+        raise SystemExit(f"--gpus {a.gpus} but WORLD_SIZE={world}")
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs an MI355X: the HIP path has no CPU fallback")
+    torch.cuda.set_device(local)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+
+    r, msg, info = build_scene(a.width, a.height, a.volume, rank, world, local)
+    if a.layout is not None:
+        r.set_layout(a.layout)
+    r.bind_uniforms()
+
+    gathered = image = slab = None
+    if world > 1:
+        from volxel_amd.dist import slab_tensor
+        slab = slab_tensor(r)
+        gathered = torch.empty(world * slab.numel(), dtype=torch.float32, device="cuda")
+        image = torch.empty(a.height * a.width * 4, dtype=torch.float32, device="cuda")
+
+    def step(f):
+        r.render(frames=1, rebind=False)
+        if world > 1:
+            r.finish()
+            dist.all_gather_into_tensor(gathered, slab)
+            torch.cuda.current_stream().synchronize()
+
+    def fence():
+        r.finish()
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier(device_ids=[local])
+        r.finish()
+        torch.cuda.synchronize()
+
+    for f in range(a.warmup):
+        step(f)
+    fence()
+    r.reset_counters()
+    t0 = time.perf_counter()
+    for f in range(a.steps):
+        step(a.warmup + f)
+    fence()
+    elapsed = time.perf_counter() - t0
+    c = r.counters()
+
+    samples, pixels, kernel_ms, slots = c.samples, c.pixels, c.kernel_ms, c.lane_slots
+    if world > 1:
+        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+        s = torch.tensor([samples, pixels], dtype=torch.float64, device="cuda")
+        dist.all_reduce(s, op=dist.ReduceOp.SUM)
+        samples, pixels = int(s[0].item()), int(s[1].item())
+        # one final de-tile so that the gathered image is materialised
+        r.detile(gathered.data_ptr(), image.data_ptr())
+        r.finish()
+
+    if rank == 0:
+        name, cus, mem = r.device_info()
+        launches = max(c.launches, 1)
+        alg_bytes_launch = (c.samples * BYTES_PER_SAMPLE + c.pixels * BYTES_PER_PIXEL) / launches
+        avg_kernel_s = c.kernel_ms / launches / 1e3
+        achieved = alg_bytes_launch / avg_kernel_s / 1e9 if avg_kernel_s > 0 else 0.0
+        out = {
+            "metric": "Gsamples/s raymarch @512^3 vol, 1080p; achieved HBM GB/s vs peak, 1/2/4/8 GPU",
+            "value": round(samples / elapsed / 1e9, 3),
+            "unit": "Gsamples/s",
+            "n_gpus": world,
+            "steps": a.steps,
+            "warmup": a.warmup,
+            "ms_per_step": round(elapsed / a.steps * 1e3, 4),
+            "higher_is_better": True,
+            "scaling": "strong",
+            "vs_baseline": None,
+            "dtype": "f32",
+            "data": "synthetic",
+            "config": {
+                "workload": f"config3: {a.volume}^3 value-noise volume (seed 42), {a.width}x{a.height}, "
+                            "DVR trilinear + 128-entry TF LUT (benchmark.json stops), step 0.5 voxel, "
+                            "ERT eps 1e-4, clip box (0.25,0,0)-(1,1,0.75)",
+                "parallelism": f"image-tiles x{world} (64x64 tiles round-robin, volume replicated, "
+                               "RCCL all_gather of the framebuffer per frame)" if world > 1 else "1 GPU",
+                "layout": "cellquad" if (a.layout in (None, 1)) else "reference",
+                "samples_per_frame": int(samples // a.steps),
+                "lane_utilisation": round(c.samples / slots, 4) if slots else None,
+                "device": name, "cus": cus, **info,
+            },
+            "roofline": {
+                "bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": None,
+                "kernel": "vx::render_dvr_cq" if a.layout in (None, 1) else "vx::render_generic<3,0>",
+                "avg_kernel_ms": round(c.kernel_ms / launches, 4),
+                "algorithmic_bytes_per_launch": int(alg_bytes_launch),
+                "rank0_gsamples_per_s_kernel_only": round(c.samples / (c.kernel_ms / 1e3) / 1e9, 3) if c.kernel_ms else None,
+            },
+        }
+        if world == 1 and not a.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(r, msg)
+        else:
+            out["cpu_baseline"] = None
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        dist.barrier(device_ids=[local])
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

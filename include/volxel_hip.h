@@ -119,6 +119,8 @@ typedef struct VxCounters {
   uint64_t pixels;       /* pixels written                                                */
   uint64_t skip_steps;   /* DDA / empty-space steps (not samples)                         */
   uint64_t grad_samples; /* samples that also evaluated the 6-tap gradient (DVR_PHONG)    */
+  uint64_t lane_slots;   /* 64 x wave iterations of the DVR march loop (samples / lane_slots
+                            = SIMD lane utilisation); 0 for kernels that do not count it   */
   uint64_t launches;     /* render-kernel launches                                        */
   double kernel_ms;      /* sum of HIP-event durations of those launches                  */
   double last_kernel_ms; /* duration of the most recent launch                            */
@@ -201,6 +203,9 @@ int vx_reset_counters(VxContext* ctx);
 int vx_device_info(VxContext* ctx, char* name_out, uint32_t name_cap, uint32_t* cu_count,
                    uint64_t* hbm_bytes);
 const char* vx_version(void);
+
+/* test hook (no reference counterpart): the device's R8-unorm decode table, 256 floats */
+int vx_debug_unorm_table(VxContext* ctx, float* out256);
 
 #ifdef __cplusplus
 }

@@ -1,0 +1,272 @@
+"""Independent NumPy restatement of RNG, brick codec and the DVR loop.  TEST INFRASTRUCTURE.
+
+Second implementation written against the reference text (not against vx_oracle.c) so that
+the two can pin each other -- the reference itself ships no vectors (PARITY UNPINNED).
+Vectorised over pixels / bricks; fused multiply-adds are emulated in float64 (exact product,
+one extra rounding in the sum: differs from a true fma only on ~2^-29 of operations).
+"""
+from __future__ import annotations
+
+import numpy as np
+
+U32 = np.uint32
+F32 = np.float32
+
+
+# ---- shaders/random.glsl -------------------------------------------------------------
+def tea(v0, v1, n=32):  # random.glsl:41-51
+    v0 = np.asarray(v0, dtype=U32).copy()
+    v1 = np.asarray(v1, dtype=U32).copy()
+    s0 = U32(0)
+    with np.errstate(over="ignore"):
+        for _ in range(n):
+            s0 = U32(s0 + U32(0x9E3779B9))
+            v0 += ((v1 << U32(4)) + U32(0xA341316C)) ^ (v1 + s0) ^ ((v1 >> U32(5)) + U32(0xC8013EA4))
+            v1 += ((v0 << U32(4)) + U32(0xAD90777D)) ^ (v0 + s0) ^ ((v0 >> U32(5)) + U32(0x7E95761E))
+    return v0
+
+
+def wang(x):  # random.glsl:59-66
+    x = np.asarray(x, dtype=U32)
+    with np.errstate(over="ignore"):
+        x = (x ^ U32(61)) ^ (x >> U32(16))
+        x = x * U32(9)
+        x = x ^ (x >> U32(4))
+        x = x * U32(0x27D4EB2D)
+        x = x ^ (x >> U32(15))
+    return x
+
+
+def rotl(x, k):
+    return (x << U32(k)) | (x >> U32(32 - k))
+
+
+class Xoshiro:
+    """vectorised state of random.glsl:69-94 (note s.x + s.z)."""
+
+    def __init__(self, seed):
+        seed = np.asarray(seed, dtype=U32)
+        with np.errstate(over="ignore"):
+            self.s = [wang(seed + U32(i)) for i in range(4)]
+
+    def next(self):
+        s = self.s
+        with np.errstate(over="ignore"):
+            result = rotl(s[0] + s[2], 7) + s[0]
+        t = s[1] << U32(9)
+        s[2] = s[2] ^ s[0]
+        s[3] = s[3] ^ s[1]
+        s[1] = s[1] ^ s[2]
+        s[0] = s[0] ^ s[3]
+        s[2] = s[2] ^ t
+        s[3] = rotl(s[3], 11)
+        return result
+
+    def rng(self):  # random.glsl:103-106
+        return (self.next() >> U32(8)).astype(F32) / F32(16777216.0)
+
+
+def pixel_seed(px, py, res_x, frame):  # fragment.frag:143
+    with np.errstate(over="ignore"):
+        idx = (np.asarray(py, dtype=U32) * U32(res_x) + np.asarray(px, dtype=U32)) * U32(42)
+    return tea(idx, np.full_like(idx, frame, dtype=U32))
+
+
+# ---- brick codec (dicom_preprocessor/src/brick.rs) --------------------------------------
+def brick_count(dims):  # brick.rs:77
+    return tuple(int(np.ceil(np.ceil(d / 8) / 8) * 8) for d in dims)
+
+
+def build_bricks(vox: np.ndarray, max_value=None):
+    """Returns dict with indirection, range_packed, atlas, atlas_size, mips, brick_counter.
+    Vectorised: padded density volume, 12^3 window min/max by strided views."""
+    vz, vy, vx = vox.shape
+    mv = int(max_value) if max_value else int(vox.max())
+    bc = brick_count((vx, vy, vz))
+    ex = tuple(b * 8 for b in bc)
+    dens = np.zeros((ex[2] + 4, ex[1] + 4, ex[0] + 4), dtype=F32)  # +-2 apron, zeros outside
+    dens[2:2 + vz, 2:2 + vy, 2:2 + vx] = vox.astype(F32) / F32(mv)
+    nb = bc[0] * bc[1] * bc[2]
+    rmin = np.empty((bc[2], bc[1], bc[0]), dtype=F32)
+    rmax = np.empty_like(rmin)
+    for bz in range(bc[2]):
+        slab = dens[bz * 8:bz * 8 + 12]
+        for by in range(bc[1]):
+            row = slab[:, by * 8:by * 8 + 12, :]
+            # windows along x: 12 wide, stride 8
+            w = np.lib.stride_tricks.sliding_window_view(row, 12, axis=2)[:, :, ::8, :]
+            rmin[bz, by] = w.min(axis=(0, 1, 3))
+            rmax[bz, by] = w.max(axis=(0, 1, 3))
+    mn16 = rmin.astype(np.float16)
+    mx16 = rmax.astype(np.float16)
+    packed = (mn16.view(np.uint16).astype(U32) << U32(16)) | mx16.view(np.uint16).astype(U32)
+    nonconst = (rmin != rmax).reshape(-1)
+    order = np.cumsum(nonconst) - 1
+    counter = int(nonconst.sum())
+    slot = np.where(nonconst, order, 0).astype(np.int64)
+    px, py, pz = slot % bc[0], (slot // bc[0]) % bc[1], slot // (bc[0] * bc[1])
+    ind = np.where(nonconst, (px | (py << 10) | (pz << 20)), 0).astype(U32)
+    slices = int(8 * np.round(np.ceil(F32(counter) / F32(bc[0] * bc[1]))))
+    atlas = np.zeros((slices, bc[1] * 8, bc[0] * 8), dtype=np.uint8)
+    rx = mn16.astype(F32).reshape(-1)
+    ry = mx16.astype(F32).reshape(-1)
+    core = dens[2:2 + ex[2], 2:2 + ex[1], 2:2 + ex[0]]
+    for bi in np.nonzero(nonconst)[0]:
+        bz, by, bx = bi // (bc[0] * bc[1]), (bi // bc[0]) % bc[1], bi % bc[0]
+        v = core[bz * 8:bz * 8 + 8, by * 8:by * 8 + 8, bx * 8:bx * 8 + 8]
+        with np.errstate(divide="ignore", invalid="ignore"):
+            n = (v - rx[bi]) / (ry[bi] - rx[bi])
+        n = np.where(n < 0, F32(0), n)
+        n = np.where(n > 1, F32(1), n)
+        r = F32(255) * n
+        r = np.where(np.isnan(r), F32(0), np.floor(np.abs(r) + F32(0.5)) * np.sign(r))  # round half away
+        q = np.clip(r, 0, 255).astype(np.uint8)
+        atlas[pz[bi] * 8:pz[bi] * 8 + 8, py[bi] * 8:py[bi] * 8 + 8, px[bi] * 8:px[bi] * 8 + 8] = q
+    mips = []
+    smin, smax = mn16.astype(F32), mx16.astype(F32)
+    for _ in range(3):
+        z, y, x = smin.shape
+        a = smin.reshape(z // 2, 2, y // 2, 2, x // 2, 2).min(axis=(1, 3, 5))
+        b = smax.reshape(z // 2, 2, y // 2, 2, x // 2, 2).max(axis=(1, 3, 5))
+        a16, b16 = a.astype(np.float16), b.astype(np.float16)
+        mips.append(((a16.view(np.uint16).astype(U32) << U32(16)) | b16.view(np.uint16).astype(U32)).reshape(-1))
+        smin, smax = a16.astype(F32), b16.astype(F32)
+    return dict(brick_count=bc, indirection=ind, range_packed=packed.reshape(-1), atlas=atlas.reshape(-1),
+                atlas_size=(bc[0] * 8, bc[1] * 8, slices), mips=mips, brick_counter=counter, nb=nb)
+
+
+# ---- shader-side lookups (sampling/common.glsl) ---------------------------------------
+def fma(a, b, c):
+    return (np.asarray(a, dtype=np.float64) * np.asarray(b, dtype=np.float64)
+            + np.asarray(c, dtype=np.float64)).astype(F32)
+
+
+class NpVolume:
+    def __init__(self, grid):
+        self.bc = tuple(grid.indirection_size)
+        self.ext = tuple(grid.index_extent)
+        self.ind = np.asarray(grid.indirection, dtype=U32)
+        r = np.asarray(grid.range, dtype=np.uint16).reshape(-1, 2)
+        self.mx = r[:, 0].view(np.float16).astype(F32)
+        self.mn = r[:, 1].view(np.float16).astype(F32)
+        self.atlas = np.asarray(grid.atlas, dtype=np.uint8)
+        self.asz = tuple(grid.atlas_size)
+
+    def brick(self, x, y, z):  # common.glsl:35-43 with OOB -> 0
+        x, y, z = [np.asarray(a, dtype=np.int64) for a in (x, y, z)]
+        ok = (x >= 0) & (y >= 0) & (z >= 0) & (x < self.ext[0]) & (y < self.ext[1]) & (z < self.ext[2])
+        xc, yc, zc = np.where(ok, x, 0), np.where(ok, y, 0), np.where(ok, z, 0)
+        bi = ((zc >> 3) * self.bc[1] + (yc >> 3)) * self.bc[0] + (xc >> 3)
+        p = self.ind[bi].astype(np.int64)
+        ax = ((p & 1023) << 3) + (xc & 7)
+        ay = (((p >> 10) & 1023) << 3) + (yc & 7)
+        az = (((p >> 20) & 1023) << 3) + (zc & 7)
+        inb = az < self.asz[2]
+        ai = np.where(inb, (az * self.asz[1] + ay) * self.asz[0] + ax, 0)
+        byte = self.atlas[ai] if self.atlas.size else np.zeros_like(ai, dtype=np.uint8)
+        un = np.where(inb, byte.astype(F32) / F32(255.0), F32(0))
+        mn, mx = self.mn[bi], self.mx[bi]
+        return np.where(ok, fma(un, mx - mn, mn), F32(0))
+
+    def trilinear(self, scale, px, py, pz):  # common.glsl:61-69
+        q = [np.asarray(a, dtype=F32) - F32(0.5) for a in (px, py, pz)]
+        fl = [np.floor(a) for a in q]
+        f = [a - b for a, b in zip(q, fl)]
+        i = [b.astype(np.int64) for b in fl]
+
+        def mix(a, b, t):
+            return fma(b, t, a * (F32(1) - t))
+
+        B = self.brick
+        lx0 = mix(B(i[0], i[1], i[2]), B(i[0] + 1, i[1], i[2]), f[0])
+        lx1 = mix(B(i[0], i[1] + 1, i[2]), B(i[0] + 1, i[1] + 1, i[2]), f[0])
+        hx0 = mix(B(i[0], i[1], i[2] + 1), B(i[0] + 1, i[1], i[2] + 1), f[0])
+        hx1 = mix(B(i[0], i[1] + 1, i[2] + 1), B(i[0] + 1, i[1] + 1, i[2] + 1), f[0])
+        return F32(scale) * mix(mix(lx0, lx1, f[1]), mix(hx0, hx1, f[1]), f[2])
+
+
+def transfer(tf, L, sr, d):  # common.glsl:78-83
+    tf = np.asarray(tf, dtype=F32).reshape(-1, 4)
+    i = np.clip(np.floor(d * F32(L)).astype(np.int64), 0, L - 1)
+    out = tf[i]
+    bad = (d < F32(sr[0])) | (d > F32(sr[1]))
+    return np.where(bad[..., None], F32(0), out)
+
+
+# ---- DVR over an image (fragment.frag main + SURVEY A12), no jitter -------------------------
+def _mat_mul(m, x, y, z, w):
+    m = np.asarray(m, dtype=F32)
+    return [fma(m[12 + i], w, fma(m[8 + i], z, fma(m[4 + i], y, m[i] * x))) for i in range(4)]
+
+
+def dvr_image(p, grid, tf, L, max_iter=100000):
+    W, H = p.res[0], p.res[1]
+    px, py = np.meshgrid(np.arange(W), np.arange(H))
+    tex_x = (px.astype(F32) + F32(0.5)) / F32(W)
+    tex_y = (py.astype(F32) + F32(0.5)) / F32(H)
+    one, zero = np.ones_like(tex_x), np.zeros_like(tex_x)
+    cw = _mat_mul(p.camera_view_inv[:], zero, zero, zero, one)
+    cam = [cw[i] / cw[3] for i in range(3)]
+    vp = _mat_mul(p.camera_proj_inv[:], fma(tex_x, F32(2), F32(-1)), fma(tex_y, F32(2), F32(-1)), zero, one)
+    vv = [vp[i] / vp[3] for i in range(3)]
+    wp = _mat_mul(p.camera_view_inv[:], vv[0], vv[1], vv[2], one)
+    d = [wp[i] / wp[3] - cam[i] for i in range(3)]
+    dd = fma(d[2], d[2], fma(d[1], d[1], d[0] * d[0]))
+    inv = F32(1) / np.sqrt(dd)
+    d = [a * inv for a in d]
+    with np.errstate(divide="ignore", invalid="ignore"):
+        lo = [(F32(p.volume_aabb_min[i]) - cam[i]) * (F32(1) / d[i]) for i in range(3)]
+        hi = [(F32(p.volume_aabb_max[i]) - cam[i]) * (F32(1) / d[i]) for i in range(3)]
+    gmin = lambda a, b: np.where(b < a, b, a)
+    gmax = lambda a, b: np.where(a < b, b, a)
+    tmin = [gmin(a, b) for a, b in zip(lo, hi)]
+    tmax = [gmax(a, b) for a, b in zip(lo, hi)]
+    near = gmax(zero, gmax(tmin[0], gmax(tmin[1], tmin[2])))
+    far = gmin(tmax[0], gmin(tmax[1], tmax[2]))
+    hit = near <= far
+    ip = _mat_mul(p.density_transform_inv[:], cam[0], cam[1], cam[2], one)
+    idr = _mat_mul(p.density_transform_inv[:], d[0], d[1], d[2], zero)
+    il = fma(idr[2], idr[2], fma(idr[1], idr[1], idr[0] * idr[0]))
+    dt = F32(p.dvr_step_voxels) / np.sqrt(il)
+    t0 = fma(F32(0.5), dt, near)
+    vol = NpVolume(grid)
+    C = [np.zeros_like(tex_x) for _ in range(3)]
+    T = np.ones_like(tex_x)
+    tau = np.zeros_like(tex_x)
+    alive = hit.copy()
+    samples = 0
+    k = 0
+    while alive.any() and k < max_iter:
+        t = fma(F32(k), dt, t0)
+        alive &= t < far
+        if not alive.any():
+            break
+        samples += int(alive.sum())
+        pos = [fma(t, idr[i], ip[i]) for i in range(3)]
+        dens = vol.trilinear(p.volume_density_scale, *pos)
+        rgba = transfer(tf, L, p.sample_range, dens * F32(p.volume_inv_maj))
+        a = np.where(alive, rgba[..., 3], F32(0))
+        pos_a = a > 0
+        tau_n = fma(a * F32(p.volume_maj), dt, tau)
+        Tn = np.exp(-tau_n.astype(np.float64)).astype(F32)
+        dT = np.where(pos_a, T - Tn, F32(0))
+        for c in range(3):
+            C[c] = np.where(pos_a, fma(dT, rgba[..., c], C[c]), C[c])
+        T = np.where(pos_a, Tn, T)
+        tau = np.where(pos_a, tau_n, tau)
+        done = pos_a & (tau >= F32(p.dvr_ert_tau))
+        T = np.where(done, F32(0), T)
+        alive &= ~done
+        k += 1
+    nl = [-F32(p.light_dir[i]) for i in range(3)]
+    cdot = gmax(fma(d[2], nl[2], fma(d[1], nl[1], d[0] * nl[0])), zero)
+    s = np.clip(np.power(cdot.astype(np.float64), 300.0), 0, 1).astype(F32)
+    env = F32(p.env_strength) * fma(s, F32(4), F32(0.01))
+    out = np.zeros((H, W, 4), dtype=F32)
+    for c in range(3):
+        Lc = C[c] * F32(p.dvr_gain[c])
+        if p.show_environment > 0:
+            Lc = np.where(T > 0, fma(T, env, Lc), Lc)
+        out[..., c] = Lc
+    out[..., 3] = 1
+    return out, samples

@@ -1,0 +1,85 @@
+"""Generates the committed golden fixtures from the CPU oracle.
+
+The reference has no tests, golden images or vectors and cannot run in
+the build image, so these fixtures are outputs of oracle/vx_oracle.c (PARITY UNPINNED).
+They pin the oracle against regressions and give the GPU parity tests fixed targets.
+
+    python -m tests.golden.make_golden      # rewrites tests/golden/*.npz, rng_kat.json
+"""
+import json
+import os
+import sys
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(os.path.dirname(HERE))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+# name -> (volume kind, n, image (w,h), mode, extra settings)
+CASES = {
+    "sphere32_debughits": ("sphere", 32, (40, 32), "dvr", dict(debug_hits=True)),
+    "sphere32_dvr": ("sphere", 32, (40, 32), "dvr", dict()),
+    "noise32_dvr_clip": ("noise", 32, (48, 40), "dvr",
+                         dict(clip_min=(0.25, 0, 0), clip_max=(1, 1, 0.75), bench=True)),
+    "noise32_dvr_jitter_f3": ("noise", 32, (32, 32), "dvr", dict(dvr_jitter=True, frame=3, bench=True)),
+    "noise32_phong": ("noise", 32, (32, 32), "dvr_phong", dict(bench=True)),
+    "noise32_raymarch": ("noise", 32, (32, 32), "raymarch", dict(bench=True, frame=2)),
+    "noise32_no_dda": ("noise", 32, (32, 32), "no_dda", dict(bench=True, frame=1)),
+    "noise32_default": ("noise", 32, (32, 32), "default", dict(bench=True, frame=4)),
+    "noise32_default_b3": ("noise", 32, (24, 24), "default", dict(bench=True, frame=6, bounces=3)),
+}
+
+
+def build_case(oracle, name):
+    from tests.common import make_scene, benchmark_tf, BENCH_CAM
+    from volxel_amd import synth
+    from volxel_amd.transfer import default_transfer_function
+    kind, n, (w, h), mode, extra = CASES[name]
+    extra = dict(extra)
+    if kind == "sphere":
+        vox, sp = synth.sphere(n)
+    else:
+        vox, sp = synth.value_noise(n, seed=5, zero_quantile=0.4)
+    grid = oracle.BrickGrid(vox, sp)
+    frame = extra.pop("frame", 0)
+    bench = extra.pop("bench", False)
+    kw = dict(extra)
+    if bench:
+        tf, L = benchmark_tf()
+        kw.update(BENCH_CAM)
+        kw.setdefault("sample_range", (0.05, 1.0))
+    else:
+        tf, L = default_transfer_function()
+    s, cam, vol, ds, p = make_scene(grid, w, h, mode, **kw)
+    return grid, tf, L, p, frame
+
+
+def render_case(oracle, name):
+    grid, tf, L, p, frame = build_case(oracle, name)
+    return oracle.render(p, grid, tf, L, frame_index=frame, threads=1)
+
+
+def main():
+    from oracle import oracle as O
+    O.build(force=True)
+    for name in CASES:
+        img, c = render_case(O, name)
+        np.savez_compressed(os.path.join(HERE, name + ".npz"), image=img, samples=np.uint64(c.samples),
+                            rays=np.uint64(c.rays))
+        print(name, img.shape, "samples", c.samples, "max", float(img[..., :3].max()))
+    L = O.lib()
+    kat = {"tea": [], "wang": [], "xoshiro": []}
+    for v0, v1 in [(0, 0), (1, 0), (0, 1), (42 * 12345, 17), (0xFFFFFFFF, 0xFFFFFFFF)]:
+        kat["tea"].append({"v0": v0, "v1": v1, "out": int(L.vxo_tea(v0, v1, 32))})
+    for x in [0, 1, 2, 3, 61, 0x12345678, 0xFFFFFFFF]:
+        kat["wang"].append({"x": x, "out": int(L.vxo_wang(x))})
+    for seed in [0, 1, 0xCAFEBABE]:
+        raw, _ = O.rng_stream(seed, 16)
+        kat["xoshiro"].append({"seed": seed, "out": [int(r) for r in raw]})
+    json.dump(kat, open(os.path.join(HERE, "rng_kat.json"), "w"), indent=1)
+
+
+if __name__ == "__main__":
+    main()

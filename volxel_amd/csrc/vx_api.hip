@@ -1,0 +1,515 @@
+// vx_api.hip -- host side of libvolxel_hip.so: the C ABI of include/volxel_hip.h.
+#include <hip/hip_runtime.h>
+
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "vx_dvr.hpp"
+#include "vx_kernels.hpp"
+
+using namespace vx;
+
+namespace {
+
+thread_local std::string g_create_error;
+
+struct EventPair {
+  hipEvent_t a, b;
+};
+
+}  // namespace
+
+struct VxContext {
+  int device = 0;
+  hipStream_t own_stream = nullptr;
+  hipStream_t stream = nullptr;
+  std::string err;
+  hipDeviceProp_t prop;
+
+  // volume
+  bool has_volume = false;
+  DevVolume dv{};
+  std::vector<void*> vol_allocs;
+  void* cq_alloc = nullptr;
+  int layout = VX_LAYOUT_CELLQUAD;
+
+  // transfer function
+  float4* tf = nullptr;
+  uint32_t tf_len = 0;
+
+  // params
+  VxParams params{};
+  bool has_params = false;
+
+  // framebuffers
+  uint32_t W = 0, H = 0;
+  TileMap tm{};
+  float4* slab = nullptr;
+  size_t slab_quads = 0;
+  float4* image = nullptr;
+  uchar4* display = nullptr;
+
+  // counters / timing
+  DevCounters* dc = nullptr;
+  std::vector<EventPair> free_events, pending_events;
+  double kernel_ms = 0.0, last_kernel_ms = 0.0;
+  uint64_t launches = 0;
+  int dvr_variant = -1;  // -1: tuned kernel; 0: generic
+};
+
+#define VX_FAIL(ctx, code, ...)                       \
+  do {                                                \
+    char buf_[512];                                   \
+    snprintf(buf_, sizeof buf_, __VA_ARGS__);         \
+    (ctx)->err = buf_;                                \
+    return (code);                                    \
+  } while (0)
+
+#define VX_HIP(ctx, expr)                                                                   \
+  do {                                                                                      \
+    hipError_t e_ = (expr);                                                                 \
+    if (e_ != hipSuccess) VX_FAIL(ctx, VX_ERR_DEVICE, "%s: %s", #expr, hipGetErrorString(e_)); \
+  } while (0)
+
+static void free_volume(VxContext* c) {
+  for (void* p : c->vol_allocs) (void)hipFree(p);
+  c->vol_allocs.clear();
+  if (c->cq_alloc) (void)hipFree(c->cq_alloc);
+  c->cq_alloc = nullptr;
+  c->dv = DevVolume{};
+  c->has_volume = false;
+}
+
+static void drain_events(VxContext* c) {
+  for (auto& e : c->pending_events) {
+    (void)hipEventSynchronize(e.b);
+    float ms = 0.f;
+    if (hipEventElapsedTime(&ms, e.a, e.b) == hipSuccess) {
+      c->kernel_ms += ms;
+      c->last_kernel_ms = ms;
+    }
+    c->free_events.push_back(e);
+  }
+  c->pending_events.clear();
+}
+
+static void update_tilemap(VxContext* c) {
+  TileMap& t = c->tm;
+  t.W = c->W;
+  t.H = c->H;
+  t.tiles_x = (c->W + VX_SHARD_TILE - 1) / VX_SHARD_TILE;
+  t.tiles_y = (c->H + VX_SHARD_TILE - 1) / VX_SHARD_TILE;
+  t.n_tiles = t.tiles_x * t.tiles_y;
+  t.shard_count = c->has_params && c->params.shard_count > 0 ? (uint32_t)c->params.shard_count : 1u;
+  t.shard_rank = c->has_params ? (uint32_t)c->params.shard_rank : 0u;
+  t.tiles_per_shard = (t.n_tiles + t.shard_count - 1) / t.shard_count;
+}
+
+static int alloc_framebuffers(VxContext* c) {
+  if (c->slab) (void)hipFree(c->slab);
+  if (c->image) (void)hipFree(c->image);
+  if (c->display) (void)hipFree(c->display);
+  c->slab = nullptr;
+  c->image = nullptr;
+  c->display = nullptr;
+  update_tilemap(c);
+  c->slab_quads = (size_t)c->tm.tiles_per_shard * 4096u;
+  if (c->slab_quads == 0) return VX_OK;
+  VX_HIP(c, hipMalloc(&c->slab, c->slab_quads * sizeof(float4)));
+  VX_HIP(c, hipMalloc(&c->image, (size_t)c->W * c->H * sizeof(float4)));
+  VX_HIP(c, hipMalloc(&c->display, (size_t)c->W * c->H * sizeof(uchar4)));
+  VX_HIP(c, hipMemsetAsync(c->slab, 0, c->slab_quads * sizeof(float4), c->stream));
+  return VX_OK;
+}
+
+template <int MODE>
+static void launch_generic(VxContext* c, uint32_t frame, float weight, dim3 grid, size_t lds) {
+  if (c->layout == VX_LAYOUT_CELLQUAD)
+    hipLaunchKernelGGL((render_generic<MODE, LAYOUT_CQ>), grid, dim3(256), lds, c->stream, c->params,
+                       c->dv, c->tf, c->tf_len, c->slab, frame, weight, c->tm, c->dc);
+  else
+    hipLaunchKernelGGL((render_generic<MODE, LAYOUT_REF>), grid, dim3(256), lds, c->stream, c->params,
+                       c->dv, c->tf, c->tf_len, c->slab, frame, weight, c->tm, c->dc);
+}
+
+extern "C" {
+
+const char* vx_version(void) { return "volxel_hip 0.1 (gfx950)"; }
+
+int vx_create(int device_id, VxContext** out) {
+  if (!out) return VX_ERR_INVALID;
+  *out = nullptr;
+  int n = 0;
+  hipError_t e = hipGetDeviceCount(&n);
+  if (e != hipSuccess || n <= 0) {
+    g_create_error = "vx_create: no HIP device visible (libvolxel_hip has no CPU fallback)";
+    return VX_ERR_NO_DEVICE;
+  }
+  if (device_id < 0 || device_id >= n) {
+    g_create_error = "vx_create: device ordinal out of range";
+    return VX_ERR_INVALID;
+  }
+  VxContext* c = new VxContext();
+  c->device = device_id;
+  if (hipSetDevice(device_id) != hipSuccess || hipGetDeviceProperties(&c->prop, device_id) != hipSuccess ||
+      hipStreamCreateWithFlags(&c->own_stream, hipStreamNonBlocking) != hipSuccess ||
+      hipMalloc(&c->dc, sizeof(DevCounters)) != hipSuccess) {
+    g_create_error = "vx_create: device initialisation failed";
+    delete c;
+    return VX_ERR_DEVICE;
+  }
+  c->stream = c->own_stream;
+  (void)hipMemset(c->dc, 0, sizeof(DevCounters));
+  const char* v = getenv("VX_DVR_KERNEL");
+  if (v && !strcmp(v, "generic")) c->dvr_variant = 0;
+  *out = c;
+  return VX_OK;
+}
+
+void vx_destroy(VxContext* c) {
+  if (!c) return;
+  (void)hipSetDevice(c->device);
+  (void)hipStreamSynchronize(c->stream);
+  drain_events(c);
+  for (auto& e : c->free_events) {
+    (void)hipEventDestroy(e.a);
+    (void)hipEventDestroy(e.b);
+  }
+  free_volume(c);
+  if (c->tf) (void)hipFree(c->tf);
+  if (c->slab) (void)hipFree(c->slab);
+  if (c->image) (void)hipFree(c->image);
+  if (c->display) (void)hipFree(c->display);
+  if (c->dc) (void)hipFree(c->dc);
+  if (c->own_stream) (void)hipStreamDestroy(c->own_stream);
+  delete c;
+}
+
+const char* vx_last_error(const VxContext* c) { return c ? c->err.c_str() : g_create_error.c_str(); }
+
+int vx_set_stream(VxContext* c, void* s) {
+  if (!c) return VX_ERR_INVALID;
+  (void)hipStreamSynchronize(c->stream);
+  c->stream = s ? (hipStream_t)s : c->own_stream;
+  return VX_OK;
+}
+
+static int build_layout(VxContext* c) {
+  if (c->cq_alloc) {
+    (void)hipFree(c->cq_alloc);
+    c->cq_alloc = nullptr;
+    c->dv.cq = nullptr;
+  }
+  if (c->layout != VX_LAYOUT_CELLQUAD) return VX_OK;
+  for (int i = 0; i < 3; ++i) c->dv.cq_bc[i] = c->dv.bc[i] + 1;
+  uint64_t n_quads = (uint64_t)c->dv.cq_bc[0] * c->dv.cq_bc[1] * c->dv.cq_bc[2] * CQ_BRICK_QUADS;
+  VX_HIP(c, hipMalloc(&c->cq_alloc, n_quads * sizeof(float4)));
+  c->dv.cq = (const float4*)c->cq_alloc;
+  uint64_t blocks = (n_quads + 255) / 256;
+  if (blocks > 0x7fffffffull) VX_FAIL(c, VX_ERR_INVALID, "volume too large for the cellquad layout");
+  hipLaunchKernelGGL(build_cellquad, dim3((uint32_t)blocks), dim3(256), 0, c->stream, c->dv,
+                     (float4*)c->cq_alloc, n_quads);
+  VX_HIP(c, hipGetLastError());
+  return VX_OK;
+}
+
+int vx_upload_volume(VxContext* c, const uint32_t* indirection, const uint32_t ind_size[3],
+                     const uint16_t* range, const uint32_t range_size[3], const uint8_t* atlas,
+                     const uint32_t atlas_size[3], int n_mips, const uint16_t* const* mip_data,
+                     const uint32_t (*mip_size)[3], const uint32_t index_extent[3]) {
+  if (!c) return VX_ERR_INVALID;
+  if (!indirection || !range || !ind_size || !range_size || !atlas_size || !index_extent)
+    VX_FAIL(c, VX_ERR_INVALID, "vx_upload_volume: null argument");
+  if (n_mips != 3 || !mip_data || !mip_size)
+    VX_FAIL(c, VX_ERR_INVALID, "vx_upload_volume: expected 3 range mipmaps (brick.rs:13)");
+  for (int i = 0; i < 3; ++i) {
+    if (ind_size[i] != range_size[i] || ind_size[i] == 0 || ind_size[i] >= 1024u)
+      VX_FAIL(c, VX_ERR_INVALID, "vx_upload_volume: bad brick grid dimensions");
+    if (index_extent[i] != ind_size[i] * 8u)
+      VX_FAIL(c, VX_ERR_INVALID, "vx_upload_volume: index_extent must be brick_count*8 (brick.rs:236-238)");
+    if (i < 2 && atlas_size[i] != ind_size[i] * 8u)
+      VX_FAIL(c, VX_ERR_INVALID, "vx_upload_volume: atlas x/y dims must be brick_count*8 (brick.rs:85)");
+  }
+  if (atlas_size[2] % 8u != 0 || atlas_size[2] > ind_size[2] * 8u)
+    VX_FAIL(c, VX_ERR_INVALID, "vx_upload_volume: bad atlas depth");
+  size_t atlas_bytes = (size_t)atlas_size[0] * atlas_size[1] * atlas_size[2];
+  if (atlas_bytes && !atlas) VX_FAIL(c, VX_ERR_INVALID, "vx_upload_volume: null atlas");
+  VX_HIP(c, hipSetDevice(c->device));
+  VX_HIP(c, hipStreamSynchronize(c->stream));
+  free_volume(c);
+  size_t nb = (size_t)ind_size[0] * ind_size[1] * ind_size[2];
+  // every pointer must address an allocated atlas brick
+  {
+    uint32_t max_slot = atlas_size[2] / 8u;
+    for (size_t i = 0; i < nb; ++i) {
+      uint32_t p = indirection[i];
+      if ((p & 1023u) >= ind_size[0] || ((p >> 10) & 1023u) >= ind_size[1] ||
+          (((p >> 20) & 1023u) >= max_slot && p != 0))
+        VX_FAIL(c, VX_ERR_INVALID, "vx_upload_volume: indirection pointer outside the atlas");
+    }
+  }
+  auto up = [&](const void* src, size_t bytes, void** dst) -> int {
+    *dst = nullptr;
+    if (bytes == 0) return VX_OK;
+    VX_HIP(c, hipMalloc(dst, bytes));
+    c->vol_allocs.push_back(*dst);
+    VX_HIP(c, hipMemcpyAsync(*dst, src, bytes, hipMemcpyHostToDevice, c->stream));
+    return VX_OK;
+  };
+  void* d = nullptr;
+  int rc;
+  if ((rc = up(indirection, nb * 4, &d))) return rc;
+  c->dv.indirection = (const uint32_t*)d;
+  if ((rc = up(range, nb * 4, &d))) return rc;  // u16 stream [max,min] == LE u32 (min<<16)|max
+  c->dv.range = (const uint32_t*)d;
+  if ((rc = up(atlas, atlas_bytes, &d))) return rc;
+  c->dv.atlas = (const uint8_t*)d;
+  for (int k = 0; k < 3; ++k) {
+    size_t n = (size_t)mip_size[k][0] * mip_size[k][1] * mip_size[k][2];
+    if (mip_size[k][0] != (ind_size[0] >> (k + 1)) || mip_size[k][1] != (ind_size[1] >> (k + 1)) ||
+        mip_size[k][2] != (ind_size[2] >> (k + 1)))
+      VX_FAIL(c, VX_ERR_INVALID, "vx_upload_volume: mip %d has wrong dimensions (brick.rs:156)", k);
+    if ((rc = up(mip_data[k], n * 4, &d))) return rc;
+    c->dv.mips[k] = (const uint32_t*)d;
+    for (int i = 0; i < 3; ++i) c->dv.mip_size[k][i] = mip_size[k][i];
+  }
+  for (int i = 0; i < 3; ++i) {
+    c->dv.bc[i] = ind_size[i];
+    c->dv.atlas_size[i] = atlas_size[i];
+    c->dv.extent[i] = index_extent[i];
+  }
+  if ((rc = build_layout(c))) return rc;
+  VX_HIP(c, hipStreamSynchronize(c->stream));  // host buffers may be dropped on return
+  c->has_volume = true;
+  return VX_OK;
+}
+
+int vx_set_layout(VxContext* c, int layout) {
+  if (!c) return VX_ERR_INVALID;
+  if (layout != VX_LAYOUT_REFERENCE && layout != VX_LAYOUT_CELLQUAD)
+    VX_FAIL(c, VX_ERR_INVALID, "vx_set_layout: unknown layout %d", layout);
+  if (layout == c->layout) return VX_OK;
+  c->layout = layout;
+  if (c->has_volume) {
+    VX_HIP(c, hipStreamSynchronize(c->stream));
+    int rc = build_layout(c);
+    if (rc) return rc;
+    VX_HIP(c, hipStreamSynchronize(c->stream));
+  }
+  return VX_OK;
+}
+
+int vx_upload_transfer(VxContext* c, const float* rgba, uint32_t length) {
+  if (!c) return VX_ERR_INVALID;
+  if (!rgba || length == 0) VX_FAIL(c, VX_ERR_INVALID, "vx_upload_transfer: empty transfer function");
+  VX_HIP(c, hipStreamSynchronize(c->stream));
+  if (c->tf) (void)hipFree(c->tf);
+  c->tf = nullptr;
+  VX_HIP(c, hipMalloc(&c->tf, (size_t)length * sizeof(float4)));
+  VX_HIP(c, hipMemcpy(c->tf, rgba, (size_t)length * sizeof(float4), hipMemcpyHostToDevice));
+  c->tf_len = length;
+  return VX_OK;
+}
+
+int vx_set_params(VxContext* c, const VxParams* p) {
+  if (!c || !p) return VX_ERR_INVALID;
+  if (p->render_mode < VX_MODE_DEFAULT || p->render_mode > VX_MODE_DVR_PHONG)
+    VX_FAIL(c, VX_ERR_INVALID, "vx_set_params: unknown render mode %d", p->render_mode);
+  if (p->shard_count < 1 || p->shard_rank < 0 || p->shard_rank >= p->shard_count)
+    VX_FAIL(c, VX_ERR_INVALID, "vx_set_params: bad shard %d/%d", p->shard_rank, p->shard_count);
+  if (p->use_env != 0)
+    VX_FAIL(c, VX_ERR_INVALID, "vx_set_params: environment-map lighting is not implemented (use_env must be 0)");
+  if (c->W && ((uint32_t)p->res[0] != c->W || (uint32_t)p->res[1] != c->H))
+    VX_FAIL(c, VX_ERR_INVALID, "vx_set_params: res %dx%d differs from vx_resize %ux%u", p->res[0],
+            p->res[1], c->W, c->H);
+  if ((p->render_mode == VX_MODE_DVR || p->render_mode == VX_MODE_DVR_PHONG) &&
+      !(p->dvr_step_voxels > 0.0f))
+    VX_FAIL(c, VX_ERR_INVALID, "vx_set_params: dvr_step_voxels must be > 0");
+  bool reshard = !c->has_params || p->shard_count != c->params.shard_count ||
+                 p->shard_rank != c->params.shard_rank;
+  c->params = *p;
+  c->has_params = true;
+  if (reshard && c->W) {
+    VX_HIP(c, hipStreamSynchronize(c->stream));
+    return alloc_framebuffers(c);
+  }
+  return VX_OK;
+}
+
+int vx_resize(VxContext* c, uint32_t w, uint32_t h) {
+  if (!c) return VX_ERR_INVALID;
+  if (w == 0 || h == 0 || w > 16384 || h > 16384) VX_FAIL(c, VX_ERR_INVALID, "vx_resize: bad size %ux%u", w, h);
+  VX_HIP(c, hipSetDevice(c->device));
+  VX_HIP(c, hipStreamSynchronize(c->stream));
+  c->W = w;
+  c->H = h;
+  return alloc_framebuffers(c);
+}
+
+int vx_render_frame(VxContext* c, uint32_t frame_index, float sample_weight) {
+  if (!c) return VX_ERR_INVALID;
+  if (!c->has_volume) VX_FAIL(c, VX_ERR_NO_VOLUME, "vx_render_frame: no volume uploaded");
+  if (!c->has_params) VX_FAIL(c, VX_ERR_INVALID, "vx_render_frame: vx_set_params not called");
+  if (!c->tf) VX_FAIL(c, VX_ERR_INVALID, "vx_render_frame: no transfer function");
+  if (!c->slab) VX_FAIL(c, VX_ERR_INVALID, "vx_render_frame: vx_resize not called");
+  if ((uint32_t)c->params.res[0] != c->W || (uint32_t)c->params.res[1] != c->H)
+    VX_FAIL(c, VX_ERR_INVALID, "vx_render_frame: params.res differs from the framebuffer size");
+  EventPair ev;
+  if (c->free_events.empty()) {
+    if (c->pending_events.size() >= 4096) drain_events(c);
+    if (c->free_events.empty()) {
+      VX_HIP(c, hipEventCreate(&ev.a));
+      VX_HIP(c, hipEventCreate(&ev.b));
+    }
+  }
+  if (!c->free_events.empty()) {
+    ev = c->free_events.back();
+    c->free_events.pop_back();
+  }
+  uint32_t groups = (c->tm.tiles_per_shard + 7u) / 8u;
+  dim3 grid(groups * 128u);
+  size_t lds = c->tf_len <= TF_LDS_MAX ? (size_t)c->tf_len * sizeof(float4) : 0;
+  VX_HIP(c, hipEventRecord(ev.a, c->stream));
+  int mode = c->params.render_mode;
+  bool tuned = (mode == VX_MODE_DVR && c->layout == VX_LAYOUT_CELLQUAD && c->dvr_variant != 0 &&
+                !c->params.debug_hits && c->tf_len <= TF_LDS_MAX);
+  if (tuned) {
+    launch_dvr_cq(c->params, c->dv, c->tf, c->tf_len, c->slab, frame_index, sample_weight, c->tm,
+                  c->dc, c->stream, c->prop.multiProcessorCount);
+  } else {
+    switch (mode) {
+      case VX_MODE_DEFAULT: launch_generic<VX_MODE_DEFAULT>(c, frame_index, sample_weight, grid, lds); break;
+      case VX_MODE_NO_DDA: launch_generic<VX_MODE_NO_DDA>(c, frame_index, sample_weight, grid, lds); break;
+      case VX_MODE_RAYMARCH: launch_generic<VX_MODE_RAYMARCH>(c, frame_index, sample_weight, grid, lds); break;
+      case VX_MODE_DVR: launch_generic<VX_MODE_DVR>(c, frame_index, sample_weight, grid, lds); break;
+      default: launch_generic<VX_MODE_DVR_PHONG>(c, frame_index, sample_weight, grid, lds); break;
+    }
+  }
+  hipError_t le = hipGetLastError();
+  VX_HIP(c, hipEventRecord(ev.b, c->stream));
+  c->pending_events.push_back(ev);
+  c->launches++;
+  if (le != hipSuccess) VX_FAIL(c, VX_ERR_DEVICE, "render kernel launch: %s", hipGetErrorString(le));
+  return VX_OK;
+}
+
+int vx_finish(VxContext* c) {
+  if (!c) return VX_ERR_INVALID;
+  VX_HIP(c, hipStreamSynchronize(c->stream));
+  return VX_OK;
+}
+
+int vx_detile(VxContext* c, const void* gathered, void* image_out) {
+  if (!c || !gathered || !image_out) return VX_ERR_INVALID;
+  dim3 grid((c->W + 15) / 16, (c->H + 15) / 16);
+  hipLaunchKernelGGL(detile, grid, dim3(256), 0, c->stream, (const float4*)gathered, (float4*)image_out, c->tm);
+  VX_HIP(c, hipGetLastError());
+  return VX_OK;
+}
+
+// own slab -> row-major image; for a sharded context the tiles of other shards read as zero
+static int own_image(VxContext* c) {
+  if (!c->slab) VX_FAIL(c, VX_ERR_INVALID, "no framebuffer (vx_resize not called)");
+  if (c->tm.shard_count == 1) return vx_detile(c, c->slab, c->image);
+  // build a temporary gathered buffer with only this shard's slab filled
+  size_t slab_bytes = c->slab_quads * sizeof(float4);
+  void* tmp = nullptr;
+  VX_HIP(c, hipMalloc(&tmp, slab_bytes * c->tm.shard_count));
+  VX_HIP(c, hipMemsetAsync(tmp, 0, slab_bytes * c->tm.shard_count, c->stream));
+  VX_HIP(c, hipMemcpyAsync((char*)tmp + slab_bytes * c->tm.shard_rank, c->slab, slab_bytes,
+                           hipMemcpyDeviceToDevice, c->stream));
+  int rc = vx_detile(c, tmp, c->image);
+  (void)hipStreamSynchronize(c->stream);
+  (void)hipFree(tmp);
+  return rc;
+}
+
+int vx_read_accum(VxContext* c, float* out) {
+  if (!c || !out) return VX_ERR_INVALID;
+  int rc = own_image(c);
+  if (rc) return rc;
+  VX_HIP(c, hipMemcpyAsync(out, c->image, (size_t)c->W * c->H * sizeof(float4), hipMemcpyDeviceToHost, c->stream));
+  VX_HIP(c, hipStreamSynchronize(c->stream));
+  return VX_OK;
+}
+
+int vx_read_display(VxContext* c, uint8_t* out, float exposure, float gamma) {
+  if (!c || !out) return VX_ERR_INVALID;
+  int rc = own_image(c);
+  if (rc) return rc;
+  uint32_t n = c->W * c->H;
+  hipLaunchKernelGGL(blit_rgba8, dim3((n + 255) / 256), dim3(256), 0, c->stream, c->image, c->display, n,
+                     exposure, gamma);
+  VX_HIP(c, hipGetLastError());
+  VX_HIP(c, hipMemcpyAsync(out, c->display, (size_t)n * 4, hipMemcpyDeviceToHost, c->stream));
+  VX_HIP(c, hipStreamSynchronize(c->stream));
+  return VX_OK;
+}
+
+int vx_slab_info(VxContext* c, uint64_t* slab_floats, uint32_t* tiles_per_shard) {
+  if (!c) return VX_ERR_INVALID;
+  if (slab_floats) *slab_floats = (uint64_t)c->slab_quads * 4u;
+  if (tiles_per_shard) *tiles_per_shard = c->tm.tiles_per_shard;
+  return VX_OK;
+}
+
+int vx_slab_device_ptr(VxContext* c, void** p) {
+  if (!c || !p) return VX_ERR_INVALID;
+  *p = c->slab;
+  return VX_OK;
+}
+
+int vx_get_counters(VxContext* c, VxCounters* out) {
+  if (!c || !out) return VX_ERR_INVALID;
+  VX_HIP(c, hipStreamSynchronize(c->stream));
+  drain_events(c);
+  DevCounters h;
+  VX_HIP(c, hipMemcpy(&h, c->dc, sizeof h, hipMemcpyDeviceToHost));
+  out->samples = h.samples;
+  out->rays = h.rays;
+  out->pixels = h.pixels;
+  out->skip_steps = h.skips;
+  out->grad_samples = h.grads;
+  out->lane_slots = h.slots;
+  out->launches = c->launches;
+  out->kernel_ms = c->kernel_ms;
+  out->last_kernel_ms = c->last_kernel_ms;
+  return VX_OK;
+}
+
+int vx_reset_counters(VxContext* c) {
+  if (!c) return VX_ERR_INVALID;
+  VX_HIP(c, hipStreamSynchronize(c->stream));
+  drain_events(c);
+  VX_HIP(c, hipMemset(c->dc, 0, sizeof(DevCounters)));
+  c->kernel_ms = c->last_kernel_ms = 0.0;
+  c->launches = 0;
+  return VX_OK;
+}
+
+int vx_device_info(VxContext* c, char* name, uint32_t cap, uint32_t* cus, uint64_t* hbm) {
+  if (!c) return VX_ERR_INVALID;
+  if (name && cap) {
+    snprintf(name, cap, "%s (%s)", c->prop.name, c->prop.gcnArchName);
+  }
+  if (cus) *cus = (uint32_t)c->prop.multiProcessorCount;
+  if (hbm) *hbm = (uint64_t)c->prop.totalGlobalMem;
+  return VX_OK;
+}
+
+// test hook (not part of the reference boundary): the device's unorm8 decode table
+int vx_debug_unorm_table(VxContext* c, float* out256) {
+  if (!c || !out256) return VX_ERR_INVALID;
+  float* d = nullptr;
+  VX_HIP(c, hipMalloc(&d, 256 * sizeof(float)));
+  hipLaunchKernelGGL(unorm_table, dim3(1), dim3(256), 0, c->stream, d);
+  VX_HIP(c, hipMemcpyAsync(out256, d, 256 * sizeof(float), hipMemcpyDeviceToHost, c->stream));
+  VX_HIP(c, hipStreamSynchronize(c->stream));
+  (void)hipFree(d);
+  return VX_OK;
+}
+
+}  // extern "C"

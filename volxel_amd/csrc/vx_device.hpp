@@ -1,0 +1,327 @@
+// vx_device.hpp -- gfx950 device functions of the Volxel ray loop.
+//
+// Restates, for CDNA4, the shader functions on the hot path:
+//   random.glsl (A1/A2), sampling/common.glsl (A4-A7), utils.glsl (A8/A9/A19),
+//   sampling/{raymarch,dda,normal}.glsl (A10-A14), fragment.frag (A15/A16).
+// Arithmetic contract (DESIGN.md "Arithmetic contract"): binary32, -ffp-contract=off, every
+// product term added to a running sum is one v_fma_f32, IEEE division / sqrt, GLSL min/max.
+// Written independently of oracle/ (which is test infrastructure and not compiled here).
+#pragma once
+
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "../../include/volxel_hip.h"
+
+#define VXD __device__ __forceinline__
+
+namespace vx {
+
+// ---------------------------------------------------------------------------------------
+// device view of an uploaded volume
+struct DevVolume {
+  // reference layout: the three textures of viewer.ts:1106-1142 as linear buffers
+  const uint32_t* indirection;  // 10-10-10 pointers            (brick.rs:30-35)
+  const uint32_t* range;        // (f16 min << 16) | f16 max    (brick.rs:19-23)
+  const uint8_t* atlas;         // u8 voxels, x fastest         (buf3d.rs:26-28)
+  const uint32_t* mips[3];      // range mips, GL levels 1..3   (brick.rs:153-190)
+  uint32_t bc[3];               // bricks per axis (= indirection = range dims)
+  uint32_t atlas_size[3];
+  uint32_t extent[3];           // padded index extent = bc*8   (brick.rs:236-238)
+  uint32_t mip_size[3][3];
+  // MI355X layout "cellquad": apron bricks of pre-decoded fp32 xy-quads
+  const float4* cq;             // [(bc+1)^3][9 slices][8][8] float4
+  uint32_t cq_bc[3];            // bc + 1
+};
+
+constexpr uint32_t CQ_SLICE_QUADS = 64;                  // 8x8 cells per z slice
+constexpr uint32_t CQ_BRICK_QUADS = 9 * CQ_SLICE_QUADS;  // 576 float4 = 9216 B
+
+// ---------------------------------------------------------------------------------------
+// arithmetic helpers
+VXD float fma_(float a, float b, float c) { return __builtin_fmaf(a, b, c); }
+VXD float gl_min(float x, float y) { return (y < x) ? y : x; }
+VXD float gl_max(float x, float y) { return (x < y) ? y : x; }
+VXD float gl_clamp(float x, float lo, float hi) { return gl_min(gl_max(x, lo), hi); }
+// truncating, saturating, NaN -> 0: v_cvt_i32_f32 (C's (int)x is undefined out of range)
+VXD int f2i(float x) {
+  int r;
+  asm("v_cvt_i32_f32 %0, %1" : "=v"(r) : "v"(x));
+  return r;
+}
+
+struct V3 {
+  float x, y, z;
+};
+VXD V3 v3(float x, float y, float z) { return V3{x, y, z}; }
+VXD float dot3(V3 a, V3 b) { return fma_(a.z, b.z, fma_(a.y, b.y, a.x * b.x)); }
+VXD V3 sub3(V3 a, V3 b) { return v3(a.x - b.x, a.y - b.y, a.z - b.z); }
+VXD V3 scale3(V3 a, float s) { return v3(a.x * s, a.y * s, a.z * s); }
+VXD V3 neg3(V3 a) { return v3(-a.x, -a.y, -a.z); }
+VXD V3 normalize3(V3 a) {
+  float inv = 1.0f / sqrtf(dot3(a, a));
+  return scale3(a, inv);
+}
+VXD V3 cross3(V3 a, V3 b) {
+  return v3(fma_(-b.y, a.z, a.y * b.z), fma_(-b.z, a.x, a.z * b.x), fma_(-b.x, a.y, a.x * b.y));
+}
+VXD V3 madd3(V3 o, float t, V3 d) {
+  return v3(fma_(t, d.x, o.x), fma_(t, d.y, o.y), fma_(t, d.z, o.z));
+}
+VXD void mat4_mul(const float* m, float x, float y, float z, float w, float out[4]) {
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+    out[i] = fma_(m[12 + i], w, fma_(m[8 + i], z, fma_(m[4 + i], y, m[i] * x)));
+}
+
+// ---------------------------------------------------------------------------------------
+// A1/A2: integer RNG, random.glsl:41-106 (bit exact)
+VXD uint32_t tea32(uint32_t v0, uint32_t v1) {  // random.glsl:41-51 with N = 32
+  uint32_t s0 = 0u;
+#pragma unroll 4
+  for (int n = 0; n < 32; ++n) {
+    s0 += 0x9e3779b9u;
+    v0 += ((v1 << 4) + 0xA341316Cu) ^ (v1 + s0) ^ ((v1 >> 5) + 0xC8013EA4u);
+    v1 += ((v0 << 4) + 0xAD90777Du) ^ (v0 + s0) ^ ((v0 >> 5) + 0x7E95761Eu);
+  }
+  return v0;
+}
+VXD uint32_t wang_hash(uint32_t x) {  // random.glsl:59-66
+  x = (x ^ 61u) ^ (x >> 16);
+  x *= 9u;
+  x = x ^ (x >> 4);
+  x *= 0x27d4eb2du;
+  x = x ^ (x >> 15);
+  return x;
+}
+struct Rng {
+  uint32_t x, y, z, w;
+};
+VXD Rng seed_xoshiro(uint32_t seed) {  // random.glsl:69-76
+  return Rng{wang_hash(seed), wang_hash(seed + 1u), wang_hash(seed + 2u), wang_hash(seed + 3u)};
+}
+VXD uint32_t rotl32(uint32_t v, uint32_t k) { return __builtin_rotateleft32(v, k); }
+VXD uint32_t xoshiro_next(Rng& s) {  // random.glsl:80-94 (s.x + s.z: quirk Q1)
+  uint32_t result = rotl32(s.x + s.z, 7u) + s.x;
+  uint32_t t = s.y << 9;
+  s.z ^= s.x;
+  s.w ^= s.y;
+  s.y ^= s.z;
+  s.x ^= s.w;
+  s.z ^= t;
+  s.w = rotl32(s.w, 11u);
+  return result;
+}
+VXD float rng(Rng& s) {  // random.glsl:103-106: exact u24 -> f32, times 2^-24
+  return (float)(xoshiro_next(s) >> 8) * 5.9604644775390625e-08f;
+}
+
+// ---------------------------------------------------------------------------------------
+// texel access on the reference layout
+VXD float half_bits_to_float(uint32_t h) {
+  _Float16 v = __builtin_bit_cast(_Float16, (uint16_t)h);
+  return (float)v;
+}
+
+// R8 unorm -> float, f = c/255 correctly rounded (GL ES 3.0 2.1.6.1) without a divide:
+// q = c*r, one Newton correction with the exact residual.  Verified for all 256 codes by
+// tests/test_gpu_parity.py::test_unorm_table.
+VXD float unorm8(uint32_t c) {
+  float fc = (float)c;
+  const float r = 1.0f / 255.0f;
+  float q = fc * r;
+  float e = fma_(-q, 255.0f, fc);
+  return fma_(e, r, q);
+}
+
+// A4: lookup_density_brick, common.glsl:35-43; out-of-range taps are 0
+VXD float lookup_density_brick(const DevVolume& v, int x, int y, int z) {
+  if ((uint32_t)x >= v.extent[0] || (uint32_t)y >= v.extent[1] || (uint32_t)z >= v.extent[2])
+    return 0.0f;
+  uint32_t bx = (uint32_t)x >> 3, by = (uint32_t)y >> 3, bz = (uint32_t)z >> 3;
+  uint32_t bi = (bz * v.bc[1] + by) * v.bc[0] + bx;
+  uint32_t rg = v.range[bi];
+  float mn = half_bits_to_float(rg >> 16), mx = half_bits_to_float(rg & 0xffffu);
+  uint32_t ptr = v.indirection[bi];
+  uint32_t ax = ((ptr & 1023u) << 3) + ((uint32_t)x & 7u);
+  uint32_t ay = (((ptr >> 10) & 1023u) << 3) + ((uint32_t)y & 7u);
+  uint32_t az = (((ptr >> 20) & 1023u) << 3) + ((uint32_t)z & 7u);
+  float un = 0.0f;  // WebGL2 robust texelFetch: outside the (pruned) atlas -> 0
+  if (az < v.atlas_size[2])
+    un = unorm8(v.atlas[((size_t)az * v.atlas_size[1] + ay) * v.atlas_size[0] + ax]);
+  return fma_(un, mx - mn, mn);
+}
+
+VXD float gl_mix(float x, float y, float a) { return fma_(y, a, x * (1.0f - a)); }
+
+enum { LAYOUT_REF = 0, LAYOUT_CQ = 1 };
+
+// A5: lookup_density_trilinear, common.glsl:61-69
+template <int LAYOUT>
+VXD float lookup_density_trilinear(const DevVolume& v, float density_scale, V3 p) {
+  float qx = p.x - 0.5f, qy = p.y - 0.5f, qz = p.z - 0.5f;
+  float flx = floorf(qx), fly = floorf(qy), flz = floorf(qz);
+  float fx = qx - flx, fy = qy - fly, fz = qz - flz;
+  int ix = f2i(flx), iy = f2i(fly), iz = f2i(flz);
+  float v000, v100, v010, v110, v001, v101, v011, v111;
+  if (LAYOUT == LAYOUT_CQ) {
+    // cell (ix,iy,iz) lives in apron brick (i+1)>>3 at local (i+1)&7; both z slices of the
+    // xy-quad are one 16-byte load each, already decoded with each tap's own brick range
+    uint32_t cx = (uint32_t)(ix + 1), cy = (uint32_t)(iy + 1), cz = (uint32_t)(iz + 1);
+    if (cx > v.extent[0] + 7u || cy > v.extent[1] + 7u || cz > v.extent[2] + 7u) return 0.0f * density_scale;
+    uint32_t b = ((cz >> 3) * v.cq_bc[1] + (cy >> 3)) * v.cq_bc[0] + (cx >> 3);
+    size_t o = (size_t)b * CQ_BRICK_QUADS + ((cz & 7u) * 64u + (cy & 7u) * 8u + (cx & 7u));
+    float4 q0 = v.cq[o];
+    float4 q1 = v.cq[o + CQ_SLICE_QUADS];
+    v000 = q0.x; v100 = q0.y; v010 = q0.z; v110 = q0.w;
+    v001 = q1.x; v101 = q1.y; v011 = q1.z; v111 = q1.w;
+  } else {
+    v000 = lookup_density_brick(v, ix, iy, iz);
+    v100 = lookup_density_brick(v, ix + 1, iy, iz);
+    v010 = lookup_density_brick(v, ix, iy + 1, iz);
+    v110 = lookup_density_brick(v, ix + 1, iy + 1, iz);
+    v001 = lookup_density_brick(v, ix, iy, iz + 1);
+    v101 = lookup_density_brick(v, ix + 1, iy, iz + 1);
+    v011 = lookup_density_brick(v, ix, iy + 1, iz + 1);
+    v111 = lookup_density_brick(v, ix + 1, iy + 1, iz + 1);
+  }
+  float lx0 = gl_mix(v000, v100, fx);
+  float lx1 = gl_mix(v010, v110, fx);
+  float hx0 = gl_mix(v001, v101, fx);
+  float hx1 = gl_mix(v011, v111, fx);
+  return density_scale * gl_mix(gl_mix(lx0, lx1, fy), gl_mix(hx0, hx1, fy), fz);
+}
+
+// lookup_majorant, common.glsl:50-53 (range texture level `mip`, .x = R = max)
+VXD float lookup_majorant(const DevVolume& v, float density_scale, V3 p, int mip) {
+  int sh = 3 + mip;
+  int bx = f2i(floorf(p.x)) >> sh, by = f2i(floorf(p.y)) >> sh, bz = f2i(floorf(p.z)) >> sh;
+  const uint32_t* data;
+  uint32_t sx, sy, sz;
+  if (mip == 0) {
+    data = v.range; sx = v.bc[0]; sy = v.bc[1]; sz = v.bc[2];
+  } else {
+    data = v.mips[mip - 1]; sx = v.mip_size[mip - 1][0]; sy = v.mip_size[mip - 1][1]; sz = v.mip_size[mip - 1][2];
+  }
+  float r = 0.0f;
+  if ((uint32_t)bx < sx && (uint32_t)by < sy && (uint32_t)bz < sz)
+    r = half_bits_to_float(data[((uint32_t)bz * sy + (uint32_t)by) * sx + (uint32_t)bx] & 0xffffu);
+  return density_scale * r;
+}
+
+// A7: lookup_transfer, common.glsl:78-83; NEAREST + CLAMP_TO_EDGE (viewer.ts:386-389)
+struct TfView {
+  const float4* lut;  // LDS or global
+  uint32_t len;
+  float lenf;
+};
+VXD float4 lookup_transfer(const TfView& tf, const float sr0, const float sr1, float d) {
+  if (d < sr0 || d > sr1) return make_float4(0.f, 0.f, 0.f, 0.f);
+  int i = f2i(floorf(d * tf.lenf));
+  i = i < 0 ? 0 : i;
+  i = i > (int)tf.len - 1 ? (int)tf.len - 1 : i;
+  return tf.lut[i];
+}
+
+// A6: stochastic_tricubic_filter, common.glsl:9-32
+VXD void stochastic_tricubic_filter(V3 ipos, Rng& s, int tap[3]) {
+  float q[3] = {ipos.x - 0.5f, ipos.y - 0.5f, ipos.z - 0.5f};
+  int ii[3], idx[3] = {0, 0, 0};
+  float t[3], t2[3], w[3], sum[3], r[3];
+  const float sixth = 1.0f / 6.0f;
+#pragma unroll
+  for (int c = 0; c < 3; ++c) {
+    ii[c] = f2i(floorf(q[c]));
+    t[c] = q[c] - (float)ii[c];
+    t2[c] = t[c] * t[c];
+    w[c] = sixth * (fma_(-3.0f, t[c], fma_(3.0f, t2[c], -t[c] * t2[c])) + 1.0f);
+    sum[c] = w[c];
+  }
+#pragma unroll
+  for (int c = 0; c < 3; ++c) {
+    w[c] = sixth * (fma_(-6.0f, t2[c], 3.0f * t[c] * t2[c]) + 4.0f);
+    sum[c] = w[c] + sum[c];
+  }
+  r[0] = rng(s); r[1] = rng(s); r[2] = rng(s);
+#pragma unroll
+  for (int c = 0; c < 3; ++c)
+    if (r[c] < w[c] / gl_max(1e-3f, sum[c])) idx[c] = 1;
+#pragma unroll
+  for (int c = 0; c < 3; ++c) {
+    w[c] = sixth * (fma_(3.0f, t[c], fma_(3.0f, t2[c], -3.0f * t[c] * t2[c])) + 1.0f);
+    sum[c] = w[c] + sum[c];
+  }
+  r[0] = rng(s); r[1] = rng(s); r[2] = rng(s);
+#pragma unroll
+  for (int c = 0; c < 3; ++c)
+    if (r[c] < w[c] / gl_max(1e-3f, sum[c])) idx[c] = 2;
+#pragma unroll
+  for (int c = 0; c < 3; ++c) {
+    w[c] = sixth * t[c] * t2[c];
+    sum[c] = w[c] + sum[c];
+  }
+  r[0] = rng(s); r[1] = rng(s); r[2] = rng(s);
+#pragma unroll
+  for (int c = 0; c < 3; ++c)
+    if (r[c] < w[c] / gl_max(1e-3f, sum[c])) idx[c] = 3;
+#pragma unroll
+  for (int c = 0; c < 3; ++c) tap[c] = ii[c] + idx[c] - 1;
+}
+
+// ---------------------------------------------------------------------------------------
+struct Ray {
+  V3 o, d;
+};
+
+// A8: ray_box_intersection, utils.glsl:61-69 (the clip box, volume.ts:32-37)
+VXD bool ray_box_intersection(const Ray& r, const float* bmin, const float* bmax, float& near,
+                              float& far) {
+  float ix = 1.0f / r.d.x, iy = 1.0f / r.d.y, iz = 1.0f / r.d.z;
+  float lox = (bmin[0] - r.o.x) * ix, loy = (bmin[1] - r.o.y) * iy, loz = (bmin[2] - r.o.z) * iz;
+  float hix = (bmax[0] - r.o.x) * ix, hiy = (bmax[1] - r.o.y) * iy, hiz = (bmax[2] - r.o.z) * iz;
+  float tminx = gl_min(lox, hix), tminy = gl_min(loy, hiy), tminz = gl_min(loz, hiz);
+  float tmaxx = gl_max(lox, hix), tmaxy = gl_max(loy, hiy), tmaxz = gl_max(loz, hiz);
+  near = gl_max(0.0f, gl_max(tminx, gl_max(tminy, tminz)));
+  far = gl_min(tmaxx, gl_min(tmaxy, tmaxz));
+  return near <= far;
+}
+
+// A9: setup_world_ray, fragment.frag:57-65 + utils.glsl:23-40, inverses hoisted (Q11)
+VXD Ray setup_world_ray(const VxParams& p, float tex_x, float tex_y, float rx, float ry) {
+  float x_off = fma_(rx, 2.0f, -1.0f) * (1.0f / (float)p.res[0]);
+  float y_off = fma_(ry, 2.0f, -1.0f) * (1.0f / (float)p.res[1]);
+  float sx = tex_x + x_off, sy = tex_y + y_off;
+  float cw[4], vp[4], wp[4];
+  mat4_mul(p.camera_view_inv, 0.0f, 0.0f, 0.0f, 1.0f, cw);
+  V3 cam = v3(cw[0] / cw[3], cw[1] / cw[3], cw[2] / cw[3]);
+  mat4_mul(p.camera_proj_inv, fma_(sx, 2.0f, -1.0f), fma_(sy, 2.0f, -1.0f), 0.0f, 1.0f, vp);
+  float vx_ = vp[0] / vp[3], vy_ = vp[1] / vp[3], vz_ = vp[2] / vp[3];
+  mat4_mul(p.camera_view_inv, vx_, vy_, vz_, 1.0f, wp);
+  V3 world = v3(wp[0] / wp[3], wp[1] / wp[3], wp[2] / wp[3]);
+  return Ray{cam, normalize3(sub3(world, cam))};
+}
+
+VXD void to_index(const VxParams& p, const Ray& r, V3& ipos, V3& idir) {
+  float a[4], b[4];
+  mat4_mul(p.density_transform_inv, r.o.x, r.o.y, r.o.z, 1.0f, a);
+  mat4_mul(p.density_transform_inv, r.d.x, r.d.y, r.d.z, 0.0f, b);
+  ipos = v3(a[0], a[1], a[2]);
+  idir = v3(b[0], b[1], b[2]);
+}
+
+// environment.glsl:19-22 directional branch; pow base clamped at 0 ([build], quirk Q16)
+VXD float lookup_environment(const VxParams& p, V3 dir) {
+  V3 nl = v3(-p.light_dir[0], -p.light_dir[1], -p.light_dir[2]);
+  float c = gl_max(dot3(dir, nl), 0.0f);
+  float s = gl_clamp(powf(c, 300.0f), 0.0f, 1.0f);
+  return p.env_strength * fma_(s, 4.0f, 0.01f);
+}
+
+VXD float sanitize1(float x) { return (x != x || __builtin_isinf(x)) ? 0.0f : x; }
+
+// per-wave work counters, flushed with one atomic per wave
+struct Counts {
+  uint32_t samples, rays, skips, grads;
+};
+
+}  // namespace vx

@@ -1,0 +1,169 @@
+// vx_dvr.hpp -- the headline kernel: deterministic front-to-back DVR (VX_MODE_DVR) on the
+// MI355X "cellquad" layout.  Same arithmetic as Frame<LAYOUT_CQ>::dvr<false> (bit-identical
+// densities, TF bins and termination decisions); exp(-tau) uses v_exp_f32.
+//
+// Shape: one wave = one 8x8-pixel tile, 4 waves (16x16 pixels) per workgroup, TF LUT in LDS,
+// two 16-byte loads per sample (the xy-quads of z-slices k and k+1 of one apron brick),
+// wave-uniform ballot to skip the compositing block while no lane sees opacity, exact
+// per-wave sample counting with s_bcnt1 on the exec mask.
+#pragma once
+#include "vx_kernels.hpp"
+
+namespace vx {
+
+struct DvrRay {
+  V3 ipos, idir;   // index-space origin / direction (raymarch.glsl:31-32)
+  float t0, dt, far;
+  float env;       // lookup_environment(dir) if show_environment
+  bool hit;
+};
+
+VXD DvrRay dvr_setup(const VxParams& p, int px, int py, uint32_t frame) {
+  Rng s = seed_xoshiro(tea32(42u * (uint32_t)(py * p.res[0] + px), frame));
+  float tex_x = ((float)px + 0.5f) / (float)p.res[0];
+  float tex_y = ((float)py + 0.5f) / (float)p.res[1];
+  float a0 = rng(s), a1 = rng(s), b0 = rng(s), b1 = rng(s);
+  float jx = (a0 + b0) / 2.0f, jy = (a1 + b1) / 2.0f;
+  (void)rng(s);
+  float u_start = rng(s);
+  float off = 0.5f;
+  if (p.dvr_jitter) off = u_start; else { jx = 0.5f; jy = 0.5f; }
+  Ray ray = setup_world_ray(p, tex_x, tex_y, jx, jy);
+  DvrRay r;
+  float near;
+  r.hit = ray_box_intersection(ray, p.volume_aabb_min, p.volume_aabb_max, near, r.far);
+  to_index(p, ray, r.ipos, r.idir);
+  r.dt = p.dvr_step_voxels / sqrtf(dot3(r.idir, r.idir));
+  r.t0 = fma_(off, r.dt, near);
+  r.env = p.show_environment > 0 ? lookup_environment(p, ray.d) : 0.0f;
+  return r;
+}
+
+__global__ __launch_bounds__(256) void render_dvr_cq(const VxParams p, const DevVolume v,
+                                                      const float4* __restrict__ tf_global,
+                                                      uint32_t tf_len, float4* __restrict__ slab,
+                                                      uint32_t frame, float weight, const TileMap tm,
+                                                      DevCounters* __restrict__ dc) {
+  extern __shared__ float4 tf_lds[];
+  for (uint32_t i = threadIdx.x; i < tf_len; i += blockDim.x) tf_lds[i] = tf_global[i];
+  __syncthreads();
+  uint32_t lt, sub;
+  if (!block_to_tile(blockIdx.x, tm, lt, sub)) return;
+  const uint32_t wt = sub * 4u + (threadIdx.x >> 6), lane = threadIdx.x & 63u;
+  int px, py;
+  uint32_t si;
+  const bool in_image = wave_pixel(tm, lt, wt, lane, px, py, si);
+
+  DvrRay r{};
+  if (in_image) r = dvr_setup(p, px, py, frame);
+  bool alive = in_image && r.hit;
+  const uint32_t n_rays = (uint32_t)__builtin_popcountll(__ballot(alive));
+
+  const float scale = p.volume_density_scale, inv_maj = p.volume_inv_maj, maj = p.volume_maj;
+  const float sr0 = p.sample_range[0], sr1 = p.sample_range[1];
+  const float lenf = (float)tf_len;
+  const int last = (int)tf_len - 1;
+  const uint32_t cbx = v.cq_bc[0], cby = v.cq_bc[1];
+  const float4* __restrict__ cq = v.cq;
+  const uint32_t cmaxx = v.extent[0] + 7u, cmaxy = v.extent[1] + 7u, cmaxz = v.extent[2] + 7u;
+  const float ert = p.dvr_ert_tau;
+  const int max_steps = p.dvr_max_steps;
+
+  float Cx = 0.f, Cy = 0.f, Cz = 0.f, T = 1.0f, tau = 0.0f, kf = 0.0f;
+  int k = 0;
+  uint32_t n_samples = 0, n_slots = 0;  // wave-uniform
+
+  while (true) {
+    float t = fma_(kf, r.dt, r.t0);
+    alive = alive && (t < r.far) && (k < max_steps);
+    unsigned long long m = __ballot(alive);
+    if (m == 0ull) break;
+    n_samples += (uint32_t)__builtin_popcountll(m);
+    n_slots += 64u;
+    if (alive) {
+      // A5 on the cellquad layout: cell (floor(p-0.5)) + 1 -> apron brick / local cell
+      float qx = fma_(t, r.idir.x, r.ipos.x) - 0.5f;
+      float qy = fma_(t, r.idir.y, r.ipos.y) - 0.5f;
+      float qz = fma_(t, r.idir.z, r.ipos.z) - 0.5f;
+      float flx = floorf(qx), fly = floorf(qy), flz = floorf(qz);
+      float fx = qx - flx, fy = qy - fly, fz = qz - flz;
+      uint32_t cx = (uint32_t)((int)flx + 1), cy = (uint32_t)((int)fly + 1), cz = (uint32_t)((int)flz + 1);
+      // inside the clipped AABB these are always in the lattice; the clamp only makes a
+      // numerically stray ray read defined memory instead of faulting
+      cx = cx < cmaxx ? cx : cmaxx; cy = cy < cmaxy ? cy : cmaxy; cz = cz < cmaxz ? cz : cmaxz;
+      uint32_t b = ((cz >> 3) * cby + (cy >> 3)) * cbx + (cx >> 3);
+      uint32_t cell = ((cz & 7u) << 6) | ((cy & 7u) << 3) | (cx & 7u);
+      const float4* qp = cq + ((size_t)b * CQ_BRICK_QUADS + cell);
+      float4 q0 = qp[0];
+      float4 q1 = qp[CQ_SLICE_QUADS];
+      float wx = 1.0f - fx, wy = 1.0f - fy, wz = 1.0f - fz;
+      float lx0 = fma_(q0.y, fx, q0.x * wx);
+      float lx1 = fma_(q0.w, fx, q0.z * wx);
+      float hx0 = fma_(q1.y, fx, q1.x * wx);
+      float hx1 = fma_(q1.w, fx, q1.z * wx);
+      float l = fma_(lx1, fy, lx0 * wy);
+      float h = fma_(hx1, fy, hx0 * wy);
+      float d = scale * fma_(h, fz, l * wz);
+      float dn = d * inv_maj;
+      // A7: NEAREST LUT, range test
+      int ti = (int)(dn * lenf);  // dn >= 0: truncation == floor
+      ti = ti > last ? last : ti;
+      ti = ti < 0 ? 0 : ti;
+      bool in_range = !(dn < sr0 || dn > sr1);
+      float4 rgba = tf_lds[ti];
+      float alpha = in_range ? rgba.w : 0.0f;
+      if (__ballot(alpha > 0.0f) != 0ull) {
+        // tau += a*maj*dt; C += (T_prev - T) * rgb   (raymarch.glsl:43 / SURVEY A12)
+        tau = fma_(alpha * maj, r.dt, tau);
+        float Tn = __builtin_amdgcn_exp2f(tau * -1.4426950408889634f);
+        Tn = alpha > 0.0f ? Tn : T;
+        float dT = T - Tn;
+        Cx = fma_(dT, rgba.x, Cx);
+        Cy = fma_(dT, rgba.y, Cy);
+        Cz = fma_(dT, rgba.z, Cz);
+        T = Tn;
+        if (tau >= ert) {
+          T = 0.0f;
+          alive = false;
+        }
+      }
+    }
+    kf += 1.0f;
+    ++k;
+  }
+
+  if (in_image) {
+    float Lx = Cx * p.dvr_gain[0], Ly = Cy * p.dvr_gain[1], Lz = Cz * p.dvr_gain[2];
+    if (p.show_environment > 0 && T > 0.0f) {
+      Lx = fma_(T, r.env, Lx);
+      Ly = fma_(T, r.env, Ly);
+      Lz = fma_(T, r.env, Lz);
+    }
+    Lx = sanitize1(Lx); Ly = sanitize1(Ly); Lz = sanitize1(Lz);
+    float4 prev = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (weight != 0.0f) prev = slab[si];
+    float4 o;
+    o.x = fma_(1.0f - weight, Lx, weight * prev.x);
+    o.y = fma_(1.0f - weight, Ly, weight * prev.y);
+    o.z = fma_(1.0f - weight, Lz, weight * prev.z);
+    o.w = 1.0f;
+    slab[si] = o;
+  }
+  const uint32_t n_px = (uint32_t)__builtin_popcountll(__ballot(in_image));
+  if (lane == 0) {
+    if (n_samples) atomicAdd(&dc->samples, (unsigned long long)n_samples);
+    if (n_rays) atomicAdd(&dc->rays, (unsigned long long)n_rays);
+    if (n_px) atomicAdd(&dc->pixels, (unsigned long long)n_px);
+    if (n_slots) atomicAdd(&dc->slots, (unsigned long long)n_slots);
+  }
+}
+
+inline void launch_dvr_cq(const VxParams& p, const DevVolume& v, const float4* tf, uint32_t tf_len,
+                          float4* slab, uint32_t frame, float weight, const TileMap& tm,
+                          DevCounters* dc, hipStream_t stream, int /*n_cus*/) {
+  uint32_t groups = (tm.tiles_per_shard + 7u) / 8u;
+  hipLaunchKernelGGL(render_dvr_cq, dim3(groups * 128u), dim3(256), (size_t)tf_len * sizeof(float4),
+                     stream, p, v, tf, tf_len, slab, frame, weight, tm, dc);
+}
+
+}  // namespace vx

@@ -1,0 +1,176 @@
+// vx_kernels.hpp -- kernels: generic per-pixel driver (all modes, both layouts), layout
+// conversion, de-tiling, display pass.
+#pragma once
+#include "vx_modes.hpp"
+
+namespace vx {
+
+// image <-> slab mapping: 64x64-pixel sharding tiles dealt
+// round-robin to shards; inside a tile 64 wave-tiles of 8x8 pixels in Morton order; the
+// accumulator ("slab") is tile-major so that one wave owns 1 KiB of contiguous pixels.
+struct TileMap {
+  uint32_t W, H;
+  uint32_t tiles_x, tiles_y, n_tiles;
+  uint32_t shard_rank, shard_count, tiles_per_shard;
+};
+
+VXD uint32_t morton_x(uint32_t m) {  // compact even bits of a 6-bit code
+  return (m & 1u) | ((m >> 1) & 2u) | ((m >> 2) & 4u);
+}
+
+// block b -> (local tile, first wave-tile).  Blocks are dealt to the 8 XCDs round-robin
+// (b % 8 = group sharing one XCD's L2): keep the 16 blocks of one 64x64 tile on one XCD and
+// hand whole tiles round-robin to the XCDs so that each L2 sees a compact piece of the
+// volume and the XCDs stay balanced.
+VXD bool block_to_tile(uint32_t b, const TileMap& tm, uint32_t& lt, uint32_t& sub) {
+  lt = (b >> 7) * 8u + (b & 7u);
+  sub = (b >> 3) & 15u;
+  return lt < tm.tiles_per_shard;
+}
+
+VXD bool wave_pixel(const TileMap& tm, uint32_t lt, uint32_t wt, uint32_t lane, int& px, int& py,
+                    uint32_t& slab_index) {
+  uint32_t t = lt * tm.shard_count + tm.shard_rank;
+  slab_index = (lt * 64u + wt) * 64u + lane;
+  if (t >= tm.n_tiles) return false;
+  uint32_t tx = t % tm.tiles_x, ty = t / tm.tiles_x;
+  px = (int)(tx * 64u + morton_x(wt) * 8u + (lane & 7u));
+  py = (int)(ty * 64u + morton_x(wt >> 1) * 8u + (lane >> 3));
+  return (uint32_t)px < tm.W && (uint32_t)py < tm.H;
+}
+
+VXD uint32_t wave_sum(uint32_t x) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) x += __shfl_down(x, o, 64);
+  return x;
+}
+
+struct DevCounters {
+  unsigned long long samples, rays, pixels, skips, grads, slots;
+};
+
+VXD void flush_counts(DevCounters* dc, const Counts& c, uint32_t pixels) {
+  uint32_t s = wave_sum(c.samples), r = wave_sum(c.rays), k = wave_sum(c.skips),
+           g = wave_sum(c.grads), px = wave_sum(pixels);
+  if ((threadIdx.x & 63u) == 0) {
+    if (s) atomicAdd(&dc->samples, (unsigned long long)s);
+    if (r) atomicAdd(&dc->rays, (unsigned long long)r);
+    if (k) atomicAdd(&dc->skips, (unsigned long long)k);
+    if (g) atomicAdd(&dc->grads, (unsigned long long)g);
+    if (px) atomicAdd(&dc->pixels, (unsigned long long)px);
+  }
+}
+
+constexpr uint32_t TF_LDS_MAX = 2048;  // entries staged in LDS (32 KiB); longer LUTs stay in L1/L2
+
+// One thread per pixel, one wave per 8x8 pixel tile, 4 waves (16x16 pixels) per block.
+template <int MODE, int LAYOUT>
+__global__ __launch_bounds__(256) void render_generic(const VxParams p, const DevVolume v,
+                                                       const float4* __restrict__ tf_global,
+                                                       uint32_t tf_len, float4* __restrict__ slab,
+                                                       uint32_t frame, float weight, const TileMap tm,
+                                                       DevCounters* __restrict__ dc) {
+  extern __shared__ float4 tf_lds[];
+  TfView tf;
+  tf.len = tf_len;
+  tf.lenf = (float)tf_len;
+  if (tf_len <= TF_LDS_MAX) {
+    for (uint32_t i = threadIdx.x; i < tf_len; i += blockDim.x) tf_lds[i] = tf_global[i];
+    __syncthreads();
+    tf.lut = tf_lds;
+  } else {
+    tf.lut = tf_global;
+  }
+  uint32_t lt, sub;
+  if (!block_to_tile(blockIdx.x, tm, lt, sub)) return;
+  uint32_t wt = sub * 4u + (threadIdx.x >> 6), lane = threadIdx.x & 63u;
+  int px, py;
+  uint32_t si;
+  bool active = wave_pixel(tm, lt, wt, lane, px, py, si);
+  Counts c{0, 0, 0, 0};
+  if (active) {
+    Frame<LAYOUT> f{p, v, tf, c};
+    float4 r = f.template shade_pixel<MODE>(px, py, frame);
+    float4 prev = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (weight != 0.0f) prev = slab[si];
+    // fragment.frag:158  out = (w*prev + (1-w)*result).rgb, alpha 1
+    float4 o;
+    o.x = fma_(1.0f - weight, r.x, weight * prev.x);
+    o.y = fma_(1.0f - weight, r.y, weight * prev.y);
+    o.z = fma_(1.0f - weight, r.z, weight * prev.z);
+    o.w = 1.0f;
+    slab[si] = o;
+  }
+  flush_counts(dc, c, active ? 1u : 0u);
+}
+
+// ---- reference layout -> cellquad (runs once per upload) -------------------------------
+// one thread per stored quad: brick' b, slice lz in [0,9), cell (ly,lx).
+__global__ __launch_bounds__(256) void build_cellquad(const DevVolume v, float4* __restrict__ out,
+                                                       uint64_t n_quads) {
+  uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n_quads) return;
+  uint32_t q = (uint32_t)(i % CQ_BRICK_QUADS);
+  uint64_t b = i / CQ_BRICK_QUADS;
+  uint32_t bx = (uint32_t)(b % v.cq_bc[0]);
+  uint32_t by = (uint32_t)((b / v.cq_bc[0]) % v.cq_bc[1]);
+  uint32_t bz = (uint32_t)(b / ((uint64_t)v.cq_bc[0] * v.cq_bc[1]));
+  uint32_t lz = q >> 6, ly = (q >> 3) & 7u, lx = q & 7u;
+  // voxel of local (l) in apron brick b: 8b - 1 + l
+  int x = (int)(bx * 8u + lx) - 1, y = (int)(by * 8u + ly) - 1, z = (int)(bz * 8u + lz) - 1;
+  float4 o;
+  o.x = lookup_density_brick(v, x, y, z);
+  o.y = lookup_density_brick(v, x + 1, y, z);
+  o.z = lookup_density_brick(v, x, y + 1, z);
+  o.w = lookup_density_brick(v, x + 1, y + 1, z);
+  out[i] = o;
+}
+
+// ---- slab(s) -> row-major image --------------------------------------------------------
+// gathered = shard_count slabs back to back (each tiles_per_shard*4096 float4)
+__global__ __launch_bounds__(256) void detile(const float4* __restrict__ gathered,
+                                               float4* __restrict__ image, const TileMap tm) {
+  uint32_t x = blockIdx.x * 16u + (threadIdx.x & 15u);
+  uint32_t y = blockIdx.y * 16u + (threadIdx.x >> 4);
+  if (x >= tm.W || y >= tm.H) return;
+  uint32_t t = (y >> 6) * tm.tiles_x + (x >> 6);
+  uint32_t shard = t % tm.shard_count, lt = t / tm.shard_count;
+  uint32_t wx = (x >> 3) & 7u, wy = (y >> 3) & 7u;
+  uint32_t wt = (wx & 1u) | ((wy & 1u) << 1) | ((wx & 2u) << 1) | ((wy & 2u) << 2) |
+                ((wx & 4u) << 2) | ((wy & 4u) << 3);
+  uint32_t lane = (y & 7u) * 8u + (x & 7u);
+  size_t si = ((size_t)shard * tm.tiles_per_shard + lt) * 4096u + wt * 64u + lane;
+  image[(size_t)y * tm.W + x] = gathered[si];
+}
+
+// ---- display pass: blit.frag:17-35 -------------------------------------------------------
+VXD float hable(float x) {
+  const float A = 0.15f, B = 0.50f, C = 0.10f, D = 0.20f, E = 0.02f, F = 0.30f;
+  float num = fma_(D, E, x * fma_(C, B, A * x));
+  float den = fma_(D, F, x * (A * x + B));
+  return num / den - E / F;
+}
+__global__ __launch_bounds__(256) void blit_rgba8(const float4* __restrict__ image,
+                                                   uchar4* __restrict__ out, uint32_t n,
+                                                   float exposure, float gamma) {
+  uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  float4 a = image[i];
+  float white = hable(11.2f), ig = 1.0f / gamma;
+  float c[4] = {powf(hable(exposure * a.x) / white, ig), powf(hable(exposure * a.y) / white, ig),
+                powf(hable(exposure * a.z) / white, ig), a.w};
+  unsigned char o[4];
+#pragma unroll
+  for (int k = 0; k < 4; ++k) {
+    float f = c[k];
+    f = (f != f) ? 0.0f : f;
+    f = f < 0.0f ? 0.0f : (f > 1.0f ? 1.0f : f);
+    o[k] = (unsigned char)f2i(floorf(fma_(f, 255.0f, 0.5f)));
+  }
+  out[i] = make_uchar4(o[0], o[1], o[2], o[3]);
+}
+
+// test hook: the unorm8 table
+__global__ void unorm_table(float* out) { out[threadIdx.x] = unorm8(threadIdx.x); }
+
+}  // namespace vx

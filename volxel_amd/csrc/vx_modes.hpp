@@ -1,0 +1,397 @@
+// vx_modes.hpp -- the march loops and the per-pixel driver (fragment.frag main) for gfx950.
+#pragma once
+#include "vx_device.hpp"
+
+namespace vx {
+
+template <int LAYOUT>
+struct Frame {
+  const VxParams& p;
+  const DevVolume& v;
+  TfView tf;
+  Counts& c;
+
+  VXD float4 transfer(float d) const { return lookup_transfer(tf, p.sample_range[0], p.sample_range[1], d); }
+  VXD float trilinear(V3 ip) const {
+    return lookup_density_trilinear<LAYOUT>(v, p.volume_density_scale, ip);
+  }
+  // lookup_density_stochastic, common.glsl:56-58,72-76
+  VXD float density_stochastic(V3 ipos, Rng& s) const {
+    int tap[3];
+    stochastic_tricubic_filter(ipos, s, tap);
+    return p.volume_density_scale * lookup_density_brick(v, tap[0], tap[1], tap[2]);
+  }
+  VXD bool slab(const Ray& r, float& near, float& far) const {
+    return ray_box_intersection(r, p.volume_aabb_min, p.volume_aabb_max, near, far);
+  }
+
+  // ---- A10/A11 RAYMARCH: sampling/raymarch.glsl ------------------------------------
+  VXD float transmittance_raymarch(const Ray& ray, Rng& s) const {  // raymarch.glsl:8-23
+    float near, far;
+    if (!slab(ray, near, far)) return 1.0f;
+    V3 ipos, idir;
+    to_index(p, ray, ipos, idir);
+    float dt = (far - near) / 64.0f;
+    near = fma_(rng(s), dt, near);
+    float tau = 0.0f;
+    for (int i = 0; i < 64; ++i) {
+      float t = gl_min(fma_((float)i, dt, near), far);
+      float d = density_stochastic(madd3(ipos, t, idir), s);
+      float4 rgba = transfer(d * p.volume_inv_maj);
+      tau = fma_(rgba.w * p.volume_maj, dt, tau);
+      c.samples++;
+    }
+    return expf(-tau);
+  }
+  VXD bool sample_raymarch(const Ray& ray, float& t, V3& thr, Rng& s) const {  // :25-55
+    float near, far;
+    if (!slab(ray, near, far)) return false;
+    V3 ipos, idir;
+    to_index(p, ray, ipos, idir);
+    float tau_target = -logf(1.0f - rng(s));
+    float dt = (far - near) / 64.0f;
+    near = fma_(rng(s), dt, near);
+    float tau = 0.0f;
+    for (int i = 0; i < 64; ++i) {
+      t = gl_min(fma_((float)i, dt, near), far);
+      float d = density_stochastic(madd3(ipos, t, idir), s);
+      float4 rgba = transfer(d * p.volume_inv_maj);
+      tau = fma_(rgba.w * p.volume_maj, dt, tau);
+      c.samples++;
+      if (tau >= tau_target) {
+        thr.x *= rgba.x * p.volume_albedo[0];
+        thr.y *= rgba.y * p.volume_albedo[1];
+        thr.z *= rgba.z * p.volume_albedo[2];
+        return true;
+      }
+    }
+    return false;
+  }
+
+  // ---- A13 default mode: sampling/dda.glsl ------------------------------------------
+  VXD static float step_dda(V3 pos, V3 inv_dir, int mip) {  // dda.glsl:11-16
+    float dim = (float)(8 << mip);
+    float inv_dim = 1.0f / dim;
+    float ox = (inv_dir.x >= 0.0f) ? dim + 0.5f : -0.5f;
+    float oy = (inv_dir.y >= 0.0f) ? dim + 0.5f : -0.5f;
+    float oz = (inv_dir.z >= 0.0f) ? dim + 0.5f : -0.5f;
+    float tx = ((floorf(pos.x * inv_dim) * dim + ox) - pos.x) * inv_dir.x;
+    float ty = ((floorf(pos.y * inv_dim) * dim + oy) - pos.y) * inv_dir.y;
+    float tz = ((floorf(pos.z * inv_dim) * dim + oz) - pos.z) * inv_dir.z;
+    return gl_min(tx, gl_min(ty, tz));
+  }
+  VXD float local_majorant(V3 curr, int mip) const {
+    float m = lookup_majorant(v, p.volume_density_scale, curr, mip);
+    return p.volume_maj * transfer(m * p.volume_inv_maj).w;
+  }
+  VXD float transmittance_dda(const Ray& ray, Rng& s) const {  // dda.glsl:21-62
+    float near, far;
+    if (!slab(ray, near, far)) return 1.0f;
+    V3 ipos, idir;
+    to_index(p, ray, ipos, idir);
+    V3 ri = v3(1.0f / idir.x, 1.0f / idir.y, 1.0f / idir.z);
+    float t = near + 1e-6f, Tr = 1.0f, tau = -logf(1.0f - rng(s)), mip = 3.0f;
+    uint32_t step = 0;
+    while (t < far && (step++ < 100u)) {
+      V3 curr = madd3(ipos, t, idir);
+      int m = f2i(roundf(mip));  // round half away from zero (quirk Q12)
+      float majorant = local_majorant(curr, m);
+      float dt = step_dda(curr, ri, m);
+      c.skips++;
+      t += dt;
+      tau = fma_(-majorant, dt, tau);
+      mip = gl_min(mip + 0.25f, 3.0f);
+      if (tau > 0.0f) continue;
+      t += tau / majorant;
+      if (t >= far) break;
+      float4 rgba = transfer(trilinear(madd3(ipos, t, idir)) * p.volume_inv_maj);
+      c.samples++;
+      float d = p.volume_maj * rgba.w;
+      if (rng(s) * majorant < d) {
+        Tr *= gl_max(0.0f, 1.0f - p.volume_maj / majorant);  // quirk Q9
+        if (Tr < 0.1f) {
+          float prob = 1.0f - Tr;
+          if (rng(s) < prob) return 0.0f;
+          Tr /= 1.0f - prob;
+        }
+      }
+      tau = -logf(1.0f - rng(s));
+      mip = gl_max(0.0f, mip - 2.0f);
+    }
+    return Tr;
+  }
+  VXD bool sample_dda(const Ray& ray, float& t, V3& thr, Rng& s) const {  // dda.glsl:65-98
+    float near, far;
+    if (!slab(ray, near, far)) return false;
+    V3 ipos, idir;
+    to_index(p, ray, ipos, idir);
+    V3 ri = v3(1.0f / idir.x, 1.0f / idir.y, 1.0f / idir.z);
+    t = near + 1e-6f;
+    float tau = -logf(1.0f - rng(s)), mip = 3.0f;
+    while (t < far) {
+      V3 curr = madd3(ipos, t, idir);
+      int m = f2i(roundf(mip));
+      float majorant = local_majorant(curr, m);
+      float dt = step_dda(curr, ri, m);
+      c.skips++;
+      t += dt;
+      tau = fma_(-majorant, dt, tau);
+      mip = gl_min(mip + 0.25f, 3.0f);
+      if (tau > 0.0f) continue;
+      t += tau / majorant;
+      if (t >= far) break;
+      float4 rgba = transfer(trilinear(madd3(ipos, t, idir)) * p.volume_inv_maj);
+      c.samples++;
+      float d = p.volume_maj * rgba.w;
+      if (rng(s) * majorant < d) {
+        thr.x *= p.volume_albedo[0]; thr.y *= p.volume_albedo[1]; thr.z *= p.volume_albedo[2];
+        thr.x *= rgba.x; thr.y *= rgba.y; thr.z *= rgba.z;
+        return true;
+      }
+      tau = -logf(1.0f - rng(s));
+      mip = gl_max(0.0f, mip - 2.0f);
+    }
+    return false;
+  }
+
+  // ---- A14 NO_DDA: sampling/normal.glsl ---------------------------------------------
+  VXD float transmittance_simple(const Ray& ray, Rng& s) const {  // normal.glsl:6-31
+    float near, far;
+    if (!slab(ray, near, far)) return 1.0f;
+    V3 ipos, idir;
+    to_index(p, ray, ipos, idir);
+    float t = fma_(-logf(1.0f - rng(s)), p.volume_inv_maj, near), Tr = 1.0f;
+    while (t < far) {
+      float4 rgba = transfer(trilinear(madd3(ipos, t, idir)) * p.volume_inv_maj);
+      c.samples++;
+      float d = p.volume_maj * rgba.w;
+      Tr *= fma_(-d, p.volume_inv_maj, 1.0f);
+      if (Tr < 0.1f) {
+        float prob = 1.0f - Tr;
+        if (rng(s) < prob) return 0.0f;
+        Tr /= 1.0f - prob;
+      }
+      t = fma_(-logf(1.0f - rng(s)), p.volume_inv_maj, t);
+    }
+    return Tr;
+  }
+  VXD bool sample_simple(const Ray& ray, float& t, V3& thr, Rng& s) const {  // :33-57
+    float near, far;
+    if (!slab(ray, near, far)) return false;
+    V3 ipos, idir;
+    to_index(p, ray, ipos, idir);
+    t = fma_(-logf(1.0f - rng(s)), p.volume_inv_maj, near);
+    while (t < far) {
+      float4 rgba = transfer(trilinear(madd3(ipos, t, idir)) * p.volume_inv_maj);
+      c.samples++;
+      float d = p.volume_maj * rgba.w;
+      float p_real = d * p.volume_inv_maj;
+      if (rng(s) < p_real) {
+        thr.x *= rgba.x * p.volume_albedo[0];
+        thr.y *= rgba.y * p.volume_albedo[1];
+        thr.z *= rgba.z * p.volume_albedo[2];
+        return true;
+      }
+      t = fma_(-logf(1.0f - rng(s)), p.volume_inv_maj, t);
+    }
+    return false;
+  }
+
+  // sampling.glsl:11-44
+  template <int MODE>
+  VXD bool sample_volume(const Ray& ray, float& t, V3& thr, Rng& s) const {
+    if (MODE == VX_MODE_NO_DDA) return sample_simple(ray, t, thr, s);
+    if (MODE == VX_MODE_RAYMARCH) return sample_raymarch(ray, t, thr, s);
+    return sample_dda(ray, t, thr, s);
+  }
+  template <int MODE>
+  VXD float transmittance(const Ray& ray, Rng& s) const {
+    if (MODE == VX_MODE_NO_DDA) return transmittance_simple(ray, s);
+    if (MODE == VX_MODE_RAYMARCH) return transmittance_raymarch(ray, s);
+    return transmittance_dda(ray, s);
+  }
+
+  // ---- utils.glsl helpers ---------------------------------------------------------------
+  VXD static float sqr(float x) { return x * x; }
+  VXD static float luma(V3 col) { return dot3(col, v3(0.212671f, 0.715160f, 0.072169f)); }
+  VXD static float power_heuristic(float a, float b) { return sqr(a) / (sqr(a) + sqr(b)); }
+  VXD static float phase_hg(float cos_t, float g) {  // utils.glsl:121-124
+    const float inv_4pi = 1.0f / (4.0f * 3.14159265358979323846f);
+    float denom = fma_(2.0f * g, cos_t, 1.0f + sqr(g));
+    return inv_4pi * (1.0f - sqr(g)) / (denom * sqrtf(denom));
+  }
+  VXD static V3 align3(V3 N, V3 w) {  // utils.glsl:106-114
+    V3 T;
+    if (fabsf(N.x) > fabsf(N.y)) {
+      float l = sqrtf(fma_(N.z, N.z, N.x * N.x));
+      T = v3(-N.z / l, 0.0f / l, N.x / l);
+    } else {
+      float l = sqrtf(fma_(N.z, N.z, N.y * N.y));
+      T = v3(0.0f / l, N.z / l, -N.y / l);
+    }
+    V3 B = cross3(N, T);
+    return normalize3(v3(fma_(w.z, N.x, fma_(w.y, B.x, w.x * T.x)),
+                         fma_(w.z, N.y, fma_(w.y, B.y, w.x * T.y)),
+                         fma_(w.z, N.z, fma_(w.y, B.z, w.x * T.z))));
+  }
+  VXD static V3 sample_phase_hg(V3 dir, float g, float u0, float u1) {  // utils.glsl:133-139
+    float cos_t;
+    if (fabsf(g) < 1e-4f) {
+      cos_t = fma_(-2.0f, u0, 1.0f);
+    } else {
+      float q = (1.0f - sqr(g)) / fma_(2.0f * g, u0, 1.0f - g);
+      cos_t = ((1.0f + sqr(g)) - sqr(q)) / (2.0f * g);
+    }
+    float sin_t = sqrtf(gl_max(0.0f, 1.0f - sqr(cos_t)));
+    float phi = 2.0f * 3.14159265358979323846f * u1;
+    return align3(dir, v3(sin_t * cosf(phi), sin_t * sinf(phi), cos_t));
+  }
+
+  // ---- A15 trace_path, fragment.frag:79-124 (directional light, environment.glsl:30-33) --
+  template <int MODE>
+  VXD float4 trace_path(Ray ray, Rng& s) const {
+    V3 L = v3(0, 0, 0), thr = v3(1, 1, 1);
+    bool free_path = true;
+    uint32_t n_paths = 0;
+    float t = 0.0f, f_p = 0.0f;
+    while (sample_volume<MODE>(ray, t, thr, s)) {
+      ray.o = madd3(ray.o, t, ray.d);
+      (void)rng(s);  // rng2 argument of sample_environment, fragment.frag:92
+      (void)rng(s);
+      V3 w_i = v3(-p.light_dir[0], -p.light_dir[1], -p.light_dir[2]);
+      float Le = p.env_strength * 4.01f;
+      const float pdf = 1.0f;
+      f_p = phase_hg(dot3(neg3(ray.d), w_i), p.volume_phase_g);
+      float mis = p.show_environment > 0 ? power_heuristic(pdf, f_p) : 1.0f;
+      float Tr = transmittance<MODE>(Ray{ray.o, w_i}, s);
+      L.x += thr.x * mis * f_p * Tr * Le / pdf;
+      L.y += thr.y * mis * f_p * Tr * Le / pdf;
+      L.z += thr.z * mis * f_p * Tr * Le / pdf;
+      if (++n_paths >= (uint32_t)p.bounces) { free_path = false; break; }
+      float rr = luma(thr);
+      if (rr < 0.1f) {
+        float prob = 1.0f - rr;
+        if (rng(s) < prob) { free_path = false; break; }
+        float q = 1.0f - prob;
+        thr = v3(thr.x / q, thr.y / q, thr.z / q);
+      }
+      float u0 = rng(s), u1 = rng(s);
+      V3 sd = sample_phase_hg(ray.d, p.volume_phase_g, u0, u1);
+      f_p = phase_hg(dot3(neg3(ray.d), sd), p.volume_phase_g);
+      ray.d = sd;
+    }
+    if (free_path && p.show_environment > 0) {
+      float Le = lookup_environment(p, ray.d);
+      // pdf_environment is 0 for the delta light ([build]); power_heuristic(f_p, 0) = 1 or NaN(0/0)
+      float mis = n_paths > 0u ? power_heuristic(f_p, 0.0f) : 1.0f;
+      L.x = fma_(thr.x * mis, Le, L.x);
+      L.y = fma_(thr.y * mis, Le, L.y);
+      L.z = fma_(thr.z * mis, Le, L.z);
+    }
+    return make_float4(L.x, L.y, L.z, gl_clamp((float)n_paths, 0.0f, 1.0f));
+  }
+
+  // ---- A12 [build] deterministic DVR (generic form; the tuned kernel is vx_dvr.hpp) ------
+  template <bool PHONG>
+  VXD float4 dvr(const Ray& ray, float start_offset) const {
+    float near, far;
+    V3 C = v3(0, 0, 0);
+    float T = 1.0f;
+    bool hit = slab(ray, near, far);
+    if (hit) {
+      c.rays++;
+      V3 ipos, idir;
+      to_index(p, ray, ipos, idir);
+      float dt = p.dvr_step_voxels / sqrtf(dot3(idir, idir));
+      float t0 = fma_(start_offset, dt, near);
+      float tau = 0.0f, kf = 0.0f;
+      V3 nl = v3(-p.light_dir[0], -p.light_dir[1], -p.light_dir[2]);
+      V3 hv = v3(0, 0, 0);
+      if (PHONG) hv = normalize3(sub3(nl, ray.d));
+      for (int i = 0; i < p.dvr_max_steps; ++i, kf += 1.0f) {
+        float t = fma_(kf, dt, t0);
+        if (!(t < far)) break;
+        V3 ip = madd3(ipos, t, idir);
+        float4 rgba = transfer(trilinear(ip) * p.volume_inv_maj);
+        c.samples++;
+        if (rgba.w > 0.0f) {
+          if (PHONG) {
+            c.grads++;
+            float gx = trilinear(v3(ip.x + 1.0f, ip.y, ip.z)) - trilinear(v3(ip.x - 1.0f, ip.y, ip.z));
+            float gy = trilinear(v3(ip.x, ip.y + 1.0f, ip.z)) - trilinear(v3(ip.x, ip.y - 1.0f, ip.z));
+            float gz = trilinear(v3(ip.x, ip.y, ip.z + 1.0f)) - trilinear(v3(ip.x, ip.y, ip.z - 1.0f));
+            V3 g = v3(gx * p.density_transform_inv[0], gy * p.density_transform_inv[5],
+                      gz * p.density_transform_inv[10]);
+            float g2 = dot3(g, g);
+            if (g2 > 1e-12f) {
+              V3 n = scale3(g, -1.0f / sqrtf(g2));
+              float ndl = gl_max(0.0f, dot3(n, nl));
+              float ndh = gl_max(0.0f, dot3(n, hv));
+              float diff = fma_(p.phong_kd, ndl, p.phong_ka);
+              float spec = p.phong_ks * powf(ndh, p.phong_shininess);
+              rgba.x = fma_(rgba.x, diff, spec);
+              rgba.y = fma_(rgba.y, diff, spec);
+              rgba.z = fma_(rgba.z, diff, spec);
+            }
+          }
+          tau = fma_(rgba.w * p.volume_maj, dt, tau);
+          float Tn = expf(-tau);
+          float dT = T - Tn;
+          C.x = fma_(dT, rgba.x, C.x);
+          C.y = fma_(dT, rgba.y, C.y);
+          C.z = fma_(dT, rgba.z, C.z);
+          T = Tn;
+          if (tau >= p.dvr_ert_tau) { T = 0.0f; break; }
+        }
+      }
+    }
+    V3 L = v3(C.x * p.dvr_gain[0], C.y * p.dvr_gain[1], C.z * p.dvr_gain[2]);
+    if (p.show_environment > 0 && T > 0.0f) {
+      float Le = lookup_environment(p, ray.d);
+      L.x = fma_(T, Le, L.x);
+      L.y = fma_(T, Le, L.y);
+      L.z = fma_(T, Le, L.z);
+    }
+    return make_float4(L.x, L.y, L.z, hit ? 1.0f : 0.0f);
+  }
+
+  // ---- fragment.frag:128-158 for one pixel (without the running-mean blend) -------------
+  template <int MODE>
+  VXD float4 shade_pixel(int px, int py, uint32_t frame) const {
+    Rng s = seed_xoshiro(tea32(42u * (uint32_t)(py * p.res[0] + px), frame));  // :143-144
+    float tex_x = ((float)px + 0.5f) / (float)p.res[0];
+    float tex_y = ((float)py + 0.5f) / (float)p.res[1];
+    float a0 = rng(s), a1 = rng(s), b0 = rng(s), b1 = rng(s);  // :146
+    float jx = (a0 + b0) / 2.0f, jy = (a1 + b1) / 2.0f;
+    constexpr bool DVR = (MODE == VX_MODE_DVR || MODE == VX_MODE_DVR_PHONG);
+    if (DVR && !p.dvr_jitter) { jx = 0.5f; jy = 0.5f; }
+    Ray ray = setup_world_ray(p, tex_x, tex_y, jx, jy);
+    float4 r;
+    if (p.debug_hits) {  // :147-153
+      float near, far;
+      if (slab(ray, near, far)) {
+        V3 h = madd3(ray.o, near, ray.d);
+        r = make_float4((h.x - p.volume_aabb_min[0]) / (p.volume_aabb_max[0] - p.volume_aabb_min[0]),
+                        (h.y - p.volume_aabb_min[1]) / (p.volume_aabb_max[1] - p.volume_aabb_min[1]),
+                        (h.z - p.volume_aabb_min[2]) / (p.volume_aabb_max[2] - p.volume_aabb_min[2]), 1.0f);
+        c.rays++;
+      } else {
+        float bg = lookup_environment(p, ray.d);
+        r = make_float4(bg, bg, bg, 1.0f);
+      }
+      return r;
+    }
+    if (DVR) {
+      (void)rng(s);  // tau_target slot of raymarch.glsl:28
+      float u_start = rng(s);
+      r = dvr<MODE == VX_MODE_DVR_PHONG>(ray, p.dvr_jitter ? u_start : 0.5f);
+    } else {
+      float near, far;
+      if (slab(ray, near, far)) c.rays++;
+      r = trace_path<MODE>(ray, s);
+    }
+    return make_float4(sanitize1(r.x), sanitize1(r.y), sanitize1(r.z), sanitize1(r.w));
+  }
+};
+
+}  // namespace vx
