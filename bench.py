@@ -13,8 +13,8 @@ in the data path) and the framebuffer is all_gathered over RCCL once per frame
 Prints ONE JSON line on rank 0 (contract in the task statement), with
   roofline     achieved algorithmic bytes (16 B/sample + 32 B/pixel) per launch /
                average HIP-event kernel duration, against the 8 TB/s HBM peak;
-  cpu_baseline the scalar CPU oracle (oracle/, kind "port") timed on this box's host cores on a
-               centred 480x270 crop of the same frame.
+  cpu_baseline the scalar CPU oracle (oracle/, kind "port") timed on this box's host cores
+               (<= 16 threads) on the same frame.
 """
 import argparse
 import json
@@ -56,14 +56,17 @@ def build_scene(width, height, n_vox, rank, world, device):
     return r, msg, info
 
 
-def cpu_baseline(r, msg, crop=(480, 270)):
-    """scalar CPU port (the parity oracle) on a centred crop of the same frame"""
+def cpu_baseline(r, msg, crop=(1920, 1080)):
+    """scalar CPU port (the parity oracle) on the same frame (or a centred crop of it),
+    on at most 16 host threads (the CPU share of a 1-GPU box)"""
     from oracle import oracle as O
     p = r.bind_uniforms()
     W, H = r.width, r.height
     x0, y0 = (W - crop[0]) // 2, (H - crop[1]) // 2
     tf, L = r._tf
-    threads = os.cpu_count() or 1
+    threads = min(os.cpu_count() or 1, 16)
+    crop = (min(crop[0], W), min(crop[1], H))
+    x0, y0 = (W - crop[0]) // 2, (H - crop[1]) // 2
     vol = O.make_volume(msg)
     t0 = time.perf_counter()
     _, c = O.render(p, vol, tf, L, frame_index=0, rect=(x0, x0 + crop[0], y0, y0 + crop[1]), threads=threads)

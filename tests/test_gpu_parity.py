@@ -219,7 +219,7 @@ def test_fullsize_properties(big_scene):
     base = r.read_accum()
     c0 = r.counters()
     assert np.isfinite(base).all() and base[..., 3].min() == 1.0
-    assert c0.pixels == 1920 * 1080 and c0.samples > 5e8
+    assert c0.pixels == 1920 * 1080 and c0.samples > 1e8
     # (a) idempotence / determinism: same frame index -> identical bits
     r.restart_rendering(); r.render()
     assert np.array_equal(r.read_accum(), base)
@@ -231,7 +231,7 @@ def test_fullsize_properties(big_scene):
     assert np.abs(ref_img - base).max() <= 2e-6
     # (c) linearity in the light: doubling env_strength doubles every pixel exactly
     r.env_strength = 2.0; r.restart_rendering(); r.render()
-    assert np.array_equal(r.read_accum(), base * 2)
+    assert np.array_equal(r.read_accum()[..., :3], base[..., :3] * 2)
     r.env_strength = 1.0
     # (d) early ray termination only removes what lies below the threshold
     eps = r.settings.dvr_ert_epsilon

@@ -77,6 +77,15 @@ def load_library():
         raise VolxelLibraryMissing(
             f"{LIB_PATH} is missing: build it with `make -C volxel_amd/csrc` "
             "(python -c 'import __graft_entry__ as g; g.build()'). There is no CPU fallback.")
+    # One HIP runtime per process: PyTorch wheels bundle their own libamdhip64.so.7 /
+    # libhsa-runtime64.so.1.  If torch is going to be used in this process (RCCL gather,
+    # zero-copy slabs) its runtime has to be loaded FIRST so that our NEEDED libamdhip64.so.7
+    # binds to the same instance; loading the system runtime first and torch's second gives
+    # two HSA runtimes and torch reports "No HIP GPUs are available".
+    try:
+        import torch  # noqa: F401
+    except Exception:  # torch absent (e.g. Node host): the system ROCm runtime is used
+        pass
     lib = C.CDLL(LIB_PATH)
     vp, u32, u64, i32 = C.c_void_p, C.c_uint32, C.c_uint64, C.c_int
     P = C.POINTER

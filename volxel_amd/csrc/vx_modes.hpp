@@ -4,6 +4,8 @@
 
 namespace vx {
 
+constexpr uint32_t LOOP_GUARD = 1u << 20;
+
 template <int LAYOUT>
 struct Frame {
   const VxParams& p;
@@ -128,7 +130,8 @@ struct Frame {
     V3 ri = v3(1.0f / idir.x, 1.0f / idir.y, 1.0f / idir.z);
     t = near + 1e-6f;
     float tau = -logf(1.0f - rng(s)), mip = 3.0f;
-    while (t < far) {
+    uint32_t guard = 0;  // the reference loop is unbounded; a wedged wave would hang the GPU
+    while (t < far && guard++ < LOOP_GUARD) {
       V3 curr = madd3(ipos, t, idir);
       int m = f2i(roundf(mip));
       float majorant = local_majorant(curr, m);
@@ -161,7 +164,8 @@ struct Frame {
     V3 ipos, idir;
     to_index(p, ray, ipos, idir);
     float t = fma_(-logf(1.0f - rng(s)), p.volume_inv_maj, near), Tr = 1.0f;
-    while (t < far) {
+    uint32_t guard = 0;
+    while (t < far && guard++ < LOOP_GUARD) {
       float4 rgba = transfer(trilinear(madd3(ipos, t, idir)) * p.volume_inv_maj);
       c.samples++;
       float d = p.volume_maj * rgba.w;
@@ -181,7 +185,8 @@ struct Frame {
     V3 ipos, idir;
     to_index(p, ray, ipos, idir);
     t = fma_(-logf(1.0f - rng(s)), p.volume_inv_maj, near);
-    while (t < far) {
+    uint32_t guard = 0;
+    while (t < far && guard++ < LOOP_GUARD) {
       float4 rgba = transfer(trilinear(madd3(ipos, t, idir)) * p.volume_inv_maj);
       c.samples++;
       float d = p.volume_maj * rgba.w;
