@@ -50,7 +50,7 @@ def test_unorm_table():
     assert "gfx950" in name and cus == 256
 
 
-@pytest.mark.parametrize("layout", [0, 1])
+@pytest.mark.parametrize("layout", [0, 1, 2])
 @pytest.mark.parametrize("name", ["sphere32_debughits", "sphere32_dvr", "noise32_dvr_clip",
                                   "noise32_dvr_jitter_f3", "noise32_phong"])
 def test_golden_deterministic(oracle, name, layout):
@@ -70,17 +70,19 @@ def test_golden_deterministic(oracle, name, layout):
         assert np.array_equal(img[box], want["image"][box])
 
 
-def test_dvr_tuned_kernel_equals_generic(oracle):
-    """the tuned cellquad kernel and the generic kernel are the same function"""
+@pytest.mark.parametrize("layout", [1, 2])
+def test_dvr_tuned_kernel_equals_generic(oracle, layout):
+    """the tuned kernels (cellquad gather, brickf32 LDS tile) and the generic kernel are the
+    same function"""
     from tests.golden.make_golden import build_case
     from volxel_amd import Volxel3DRenderer
     grid, tf, L, p, frame = build_case(oracle, "noise32_dvr_clip")
-    r = _renderer(grid, tf, L, p, 1)
+    r = _renderer(grid, tf, L, p, layout)
     a = _render_with_params(r, p, frame)
     ca = r.counters()
     os.environ["VX_DVR_KERNEL"] = "generic"
     try:
-        r2 = _renderer(grid, tf, L, p, 1)
+        r2 = _renderer(grid, tf, L, p, layout)
     finally:
         del os.environ["VX_DVR_KERNEL"]
     b = _render_with_params(r2, p, frame)
@@ -90,7 +92,7 @@ def test_dvr_tuned_kernel_equals_generic(oracle):
     assert np.abs(a - b).max() <= 2e-6
 
 
-@pytest.mark.parametrize("layout", [0, 1])
+@pytest.mark.parametrize("layout", [0, 1, 2])
 @pytest.mark.parametrize("name", ["noise32_raymarch", "noise32_no_dda", "noise32_default",
                                   "noise32_default_b3"])
 def test_golden_stochastic_modes(oracle, name, layout):
@@ -118,7 +120,7 @@ def test_config1_sphere_256_live_oracle(oracle):
     for mode, kw in (("dvr", {}), ("dvr", dict(debug_hits=True))):
         s, cam, vol, ds, p = make_scene(g, 256, 256, mode, **kw)
         want, oc = oracle.render(p, g, tf, L)
-        for layout in (0, 1):
+        for layout in (0, 1, 2):
             r = _renderer(g, tf, L, p, layout)
             img = _render_with_params(r, p)
             c = r.counters()
@@ -140,11 +142,12 @@ def test_ct_phantom_clip_anisotropic_live_oracle(oracle):
                                     density_multiplier=0.99, clip_min=(0.25, 0, 0), clip_max=(1, 1, 0.75),
                                     **BENCH_CAM)
     want, oc = oracle.render(p, og, tf, L)
-    r = _renderer(msg, tf, L, p, 1)
-    img = _render_with_params(r, p)
-    c = r.counters()
-    assert np.abs(img - want).max() <= 2e-6
-    assert c.samples == oc.samples
+    for layout in (1, 2):
+        r = _renderer(msg, tf, L, p, layout)
+        img = _render_with_params(r, p)
+        c = r.counters()
+        assert np.abs(img - want).max() <= 2e-6
+        assert c.samples == oc.samples
 
 
 def test_progressive_accumulation_matches_oracle(oracle):
@@ -155,7 +158,7 @@ def test_progressive_accumulation_matches_oracle(oracle):
     g = oracle.BrickGrid(vox, sp)
     tf, L = benchmark_tf()
     s, cam, vol, ds, p = make_scene(g, 64, 48, "dvr", dvr_jitter=True, sample_range=(0.05, 1.0), **BENCH_CAM)
-    r = _renderer(g, tf, L, p, 1)
+    r = _renderer(g, tf, L, p, 2)
     prev = None
     for f in range(8):
         w = sample_weight(f)
@@ -223,12 +226,13 @@ def test_fullsize_properties(big_scene):
     # (a) idempotence / determinism: same frame index -> identical bits
     r.restart_rendering(); r.render()
     assert np.array_equal(r.read_accum(), base)
-    # (b) layout independence: reference-layout kernel gives the same densities, bins, counts
-    r.set_layout(0); r.restart_rendering(); r.reset_counters(); r.render()
-    ref_img = r.read_accum(); c1 = r.counters()
-    r.set_layout(1)
-    assert c1.samples == c0.samples and c1.rays == c0.rays
-    assert np.abs(ref_img - base).max() <= 2e-6
+    # (b) layout independence: every layout / kernel gives the same densities, bins, counts
+    for layout in (0, 1):
+        r.set_layout(layout); r.restart_rendering(); r.reset_counters(); r.render()
+        ref_img = r.read_accum(); c1 = r.counters()
+        assert c1.samples == c0.samples and c1.rays == c0.rays
+        assert np.abs(ref_img - base).max() <= 2e-6
+    r.set_layout(2)
     # (c) linearity in the light: doubling env_strength doubles every pixel exactly
     r.env_strength = 2.0; r.restart_rendering(); r.render()
     assert np.array_equal(r.read_accum()[..., :3], base[..., :3] * 2)

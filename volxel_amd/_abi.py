@@ -48,7 +48,7 @@ VxParams = struct_from_header("volxel_hip.h", "VxParams")
 VxCounters = struct_from_header("volxel_hip.h", "VxCounters")
 
 MODE_DEFAULT, MODE_NO_DDA, MODE_RAYMARCH, MODE_DVR, MODE_DVR_PHONG = range(5)
-LAYOUT_REFERENCE, LAYOUT_CELLQUAD = 0, 1
+LAYOUT_REFERENCE, LAYOUT_CELLQUAD, LAYOUT_BRICKF32 = 0, 1, 2
 RENDER_MODES = {"default": MODE_DEFAULT, "no_dda": MODE_NO_DDA, "raymarch": MODE_RAYMARCH,
                 "dvr": MODE_DVR, "dvr_phong": MODE_DVR_PHONG}
 SHARD_TILE = 64

@@ -8,6 +8,7 @@
 #include <vector>
 
 #include "vx_dvr.hpp"
+#include "vx_dvr_tile.hpp"
 #include "vx_kernels.hpp"
 
 using namespace vx;
@@ -34,7 +35,8 @@ struct VxContext {
   DevVolume dv{};
   std::vector<void*> vol_allocs;
   void* cq_alloc = nullptr;
-  int layout = VX_LAYOUT_CELLQUAD;
+  void* bf_alloc = nullptr;
+  int layout = VX_LAYOUT_BRICKF32;
 
   // transfer function
   float4* tf = nullptr;
@@ -53,7 +55,9 @@ struct VxContext {
   uchar4* display = nullptr;
 
   // counters / timing
-  DevCounters* dc = nullptr;
+  DevCounters* dc = nullptr;   // one record per wave of the largest launch grid
+  size_t dc_waves = 0;
+  VxCounters base{};           // totals folded in when the record array is reallocated
   std::vector<EventPair> free_events, pending_events;
   double kernel_ms = 0.0, last_kernel_ms = 0.0;
   uint64_t launches = 0;
@@ -78,7 +82,9 @@ static void free_volume(VxContext* c) {
   for (void* p : c->vol_allocs) (void)hipFree(p);
   c->vol_allocs.clear();
   if (c->cq_alloc) (void)hipFree(c->cq_alloc);
+  if (c->bf_alloc) (void)hipFree(c->bf_alloc);
   c->cq_alloc = nullptr;
+  c->bf_alloc = nullptr;
   c->dv = DevVolume{};
   c->has_volume = false;
 }
@@ -125,9 +131,43 @@ static int alloc_framebuffers(VxContext* c) {
   return VX_OK;
 }
 
+
+static int fold_counters(VxContext* c) {
+  if (!c->dc || !c->dc_waves) return VX_OK;
+  std::vector<DevCounters> h(c->dc_waves);
+  VX_HIP(c, hipMemcpy(h.data(), c->dc, h.size() * sizeof(DevCounters), hipMemcpyDeviceToHost));
+  for (const auto& w : h) {
+    c->base.samples += w.samples;
+    c->base.lane_slots += w.slots;
+    c->base.rays += w.rays;
+    c->base.pixels += w.pixels;
+    c->base.skip_steps += w.skips;
+    c->base.grad_samples += w.grads;
+  }
+  VX_HIP(c, hipMemset(c->dc, 0, c->dc_waves * sizeof(DevCounters)));
+  return VX_OK;
+}
+
+static int ensure_counters(VxContext* c, size_t waves) {
+  if (waves <= c->dc_waves) return VX_OK;
+  VX_HIP(c, hipStreamSynchronize(c->stream));
+  int rc = fold_counters(c);
+  if (rc) return rc;
+  if (c->dc) (void)hipFree(c->dc);
+  c->dc = nullptr;
+  c->dc_waves = 0;
+  VX_HIP(c, hipMalloc(&c->dc, waves * sizeof(DevCounters)));
+  VX_HIP(c, hipMemset(c->dc, 0, waves * sizeof(DevCounters)));
+  c->dc_waves = waves;
+  return VX_OK;
+}
+
 template <int MODE>
 static void launch_generic(VxContext* c, uint32_t frame, float weight, dim3 grid, size_t lds) {
-  if (c->layout == VX_LAYOUT_CELLQUAD)
+  if (c->layout == VX_LAYOUT_BRICKF32)
+    hipLaunchKernelGGL((render_generic<MODE, LAYOUT_BF>), grid, dim3(256), lds, c->stream, c->params,
+                       c->dv, c->tf, c->tf_len, c->slab, frame, weight, c->tm, c->dc);
+  else if (c->layout == VX_LAYOUT_CELLQUAD)
     hipLaunchKernelGGL((render_generic<MODE, LAYOUT_CQ>), grid, dim3(256), lds, c->stream, c->params,
                        c->dv, c->tf, c->tf_len, c->slab, frame, weight, c->tm, c->dc);
   else
@@ -155,14 +195,12 @@ int vx_create(int device_id, VxContext** out) {
   VxContext* c = new VxContext();
   c->device = device_id;
   if (hipSetDevice(device_id) != hipSuccess || hipGetDeviceProperties(&c->prop, device_id) != hipSuccess ||
-      hipStreamCreateWithFlags(&c->own_stream, hipStreamNonBlocking) != hipSuccess ||
-      hipMalloc(&c->dc, sizeof(DevCounters)) != hipSuccess) {
+      hipStreamCreateWithFlags(&c->own_stream, hipStreamNonBlocking) != hipSuccess) {
     g_create_error = "vx_create: device initialisation failed";
     delete c;
     return VX_ERR_DEVICE;
   }
   c->stream = c->own_stream;
-  (void)hipMemset(c->dc, 0, sizeof(DevCounters));
   const char* v = getenv("VX_DVR_KERNEL");
   if (v && !strcmp(v, "generic")) c->dvr_variant = 0;
   *out = c;
@@ -202,6 +240,20 @@ static int build_layout(VxContext* c) {
     (void)hipFree(c->cq_alloc);
     c->cq_alloc = nullptr;
     c->dv.cq = nullptr;
+  }
+  if (c->bf_alloc) {
+    (void)hipFree(c->bf_alloc);
+    c->bf_alloc = nullptr;
+    c->dv.bf = nullptr;
+  }
+  if (c->layout == VX_LAYOUT_BRICKF32) {
+    uint64_t n_vox = (uint64_t)c->dv.bc[0] * c->dv.bc[1] * c->dv.bc[2] * 512u;
+    VX_HIP(c, hipMalloc(&c->bf_alloc, n_vox * sizeof(float)));
+    c->dv.bf = (const float*)c->bf_alloc;
+    hipLaunchKernelGGL(build_brickf32, dim3((uint32_t)((n_vox + 255) / 256)), dim3(256), 0, c->stream,
+                       c->dv, (float*)c->bf_alloc, n_vox);
+    VX_HIP(c, hipGetLastError());
+    return VX_OK;
   }
   if (c->layout != VX_LAYOUT_CELLQUAD) return VX_OK;
   for (int i = 0; i < 3; ++i) c->dv.cq_bc[i] = c->dv.bc[i] + 1;
@@ -289,7 +341,7 @@ int vx_upload_volume(VxContext* c, const uint32_t* indirection, const uint32_t i
 
 int vx_set_layout(VxContext* c, int layout) {
   if (!c) return VX_ERR_INVALID;
-  if (layout != VX_LAYOUT_REFERENCE && layout != VX_LAYOUT_CELLQUAD)
+  if (layout != VX_LAYOUT_REFERENCE && layout != VX_LAYOUT_CELLQUAD && layout != VX_LAYOUT_BRICKF32)
     VX_FAIL(c, VX_ERR_INVALID, "vx_set_layout: unknown layout %d", layout);
   if (layout == c->layout) return VX_OK;
   c->layout = layout;
@@ -371,12 +423,19 @@ int vx_render_frame(VxContext* c, uint32_t frame_index, float sample_weight) {
   }
   uint32_t groups = (c->tm.tiles_per_shard + 7u) / 8u;
   dim3 grid(groups * 128u);
+  {
+    int rc = ensure_counters(c, (size_t)grid.x * 4u);
+    if (rc) return rc;
+  }
   size_t lds = c->tf_len <= TF_LDS_MAX ? (size_t)c->tf_len * sizeof(float4) : 0;
   VX_HIP(c, hipEventRecord(ev.a, c->stream));
   int mode = c->params.render_mode;
-  bool tuned = (mode == VX_MODE_DVR && c->layout == VX_LAYOUT_CELLQUAD && c->dvr_variant != 0 &&
+  bool tuned = (mode == VX_MODE_DVR && c->layout != VX_LAYOUT_REFERENCE && c->dvr_variant != 0 &&
                 !c->params.debug_hits && c->tf_len <= TF_LDS_MAX);
-  if (tuned) {
+  if (tuned && c->layout == VX_LAYOUT_BRICKF32) {
+    launch_dvr_tile(c->params, c->dv, c->tf, c->tf_len, c->slab, frame_index, sample_weight, c->tm,
+                    c->dc, c->stream);
+  } else if (tuned) {
     launch_dvr_cq(c->params, c->dv, c->tf, c->tf_len, c->slab, frame_index, sample_weight, c->tm,
                   c->dc, c->stream, c->prop.multiProcessorCount);
   } else {
@@ -466,14 +525,14 @@ int vx_get_counters(VxContext* c, VxCounters* out) {
   if (!c || !out) return VX_ERR_INVALID;
   VX_HIP(c, hipStreamSynchronize(c->stream));
   drain_events(c);
-  DevCounters h;
-  VX_HIP(c, hipMemcpy(&h, c->dc, sizeof h, hipMemcpyDeviceToHost));
-  out->samples = h.samples;
-  out->rays = h.rays;
-  out->pixels = h.pixels;
-  out->skip_steps = h.skips;
-  out->grad_samples = h.grads;
-  out->lane_slots = h.slots;
+  int rc = fold_counters(c);
+  if (rc) return rc;
+  out->samples = c->base.samples;
+  out->rays = c->base.rays;
+  out->pixels = c->base.pixels;
+  out->skip_steps = c->base.skip_steps;
+  out->grad_samples = c->base.grad_samples;
+  out->lane_slots = c->base.lane_slots;
   out->launches = c->launches;
   out->kernel_ms = c->kernel_ms;
   out->last_kernel_ms = c->last_kernel_ms;
@@ -484,7 +543,8 @@ int vx_reset_counters(VxContext* c) {
   if (!c) return VX_ERR_INVALID;
   VX_HIP(c, hipStreamSynchronize(c->stream));
   drain_events(c);
-  VX_HIP(c, hipMemset(c->dc, 0, sizeof(DevCounters)));
+  if (c->dc) VX_HIP(c, hipMemset(c->dc, 0, c->dc_waves * sizeof(DevCounters)));
+  c->base = VxCounters{};
   c->kernel_ms = c->last_kernel_ms = 0.0;
   c->launches = 0;
   return VX_OK;

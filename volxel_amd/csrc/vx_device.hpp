@@ -32,6 +32,8 @@ struct DevVolume {
   // MI355X layout "cellquad": apron bricks of pre-decoded fp32 xy-quads
   const float4* cq;             // [(bc+1)^3][9 slices][8][8] float4
   uint32_t cq_bc[3];            // bc + 1
+  // MI355X layout "brickf32": every 8^3 brick decoded to fp32, 2 KiB contiguous, brick-major
+  const float* bf;              // [bc.z][bc.y][bc.x][8][8][8]
 };
 
 constexpr uint32_t CQ_SLICE_QUADS = 64;                  // 8x8 cells per z slice
@@ -154,7 +156,16 @@ VXD float lookup_density_brick(const DevVolume& v, int x, int y, int z) {
 
 VXD float gl_mix(float x, float y, float a) { return fma_(y, a, x * (1.0f - a)); }
 
-enum { LAYOUT_REF = 0, LAYOUT_CQ = 1 };
+enum { LAYOUT_REF = 0, LAYOUT_CQ = 1, LAYOUT_BF = 2 };
+
+// decoded voxel from the brickf32 layout; out-of-range taps are 0
+VXD float bf_voxel(const DevVolume& v, int x, int y, int z) {
+  if ((uint32_t)x >= v.extent[0] || (uint32_t)y >= v.extent[1] || (uint32_t)z >= v.extent[2])
+    return 0.0f;
+  uint32_t b = (((uint32_t)z >> 3) * v.bc[1] + ((uint32_t)y >> 3)) * v.bc[0] + ((uint32_t)x >> 3);
+  uint32_t l = (((uint32_t)z & 7u) << 6) | (((uint32_t)y & 7u) << 3) | ((uint32_t)x & 7u);
+  return v.bf[(size_t)b * 512u + l];
+}
 
 // A5: lookup_density_trilinear, common.glsl:61-69
 template <int LAYOUT>
@@ -175,6 +186,15 @@ VXD float lookup_density_trilinear(const DevVolume& v, float density_scale, V3 p
     float4 q1 = v.cq[o + CQ_SLICE_QUADS];
     v000 = q0.x; v100 = q0.y; v010 = q0.z; v110 = q0.w;
     v001 = q1.x; v101 = q1.y; v011 = q1.z; v111 = q1.w;
+  } else if (LAYOUT == LAYOUT_BF) {
+    v000 = bf_voxel(v, ix, iy, iz);
+    v100 = bf_voxel(v, ix + 1, iy, iz);
+    v010 = bf_voxel(v, ix, iy + 1, iz);
+    v110 = bf_voxel(v, ix + 1, iy + 1, iz);
+    v001 = bf_voxel(v, ix, iy, iz + 1);
+    v101 = bf_voxel(v, ix + 1, iy, iz + 1);
+    v011 = bf_voxel(v, ix, iy + 1, iz + 1);
+    v111 = bf_voxel(v, ix + 1, iy + 1, iz + 1);
   } else {
     v000 = lookup_density_brick(v, ix, iy, iz);
     v100 = lookup_density_brick(v, ix + 1, iy, iz);

@@ -14,20 +14,22 @@ namespace vx {
 struct DvrRay {
   V3 ipos, idir;   // index-space origin / direction (raymarch.glsl:31-32)
   float t0, dt, far;
-  float env;       // lookup_environment(dir) if show_environment
+  V3 wdir;         // world-space direction (for the environment term)
   bool hit;
 };
 
 VXD DvrRay dvr_setup(const VxParams& p, int px, int py, uint32_t frame) {
-  Rng s = seed_xoshiro(tea32(42u * (uint32_t)(py * p.res[0] + px), frame));
   float tex_x = ((float)px + 0.5f) / (float)p.res[0];
   float tex_y = ((float)py + 0.5f) / (float)p.res[1];
-  float a0 = rng(s), a1 = rng(s), b0 = rng(s), b1 = rng(s);
-  float jx = (a0 + b0) / 2.0f, jy = (a1 + b1) / 2.0f;
-  (void)rng(s);
-  float u_start = rng(s);
-  float off = 0.5f;
-  if (p.dvr_jitter) off = u_start; else { jx = 0.5f; jy = 0.5f; }
+  float jx = 0.5f, jy = 0.5f, off = 0.5f;
+  if (p.dvr_jitter) {  // wave-uniform: the integer RNG (32 TEA rounds) only runs when it is used
+    Rng s = seed_xoshiro(tea32(42u * (uint32_t)(py * p.res[0] + px), frame));
+    float a0 = rng(s), a1 = rng(s), b0 = rng(s), b1 = rng(s);
+    jx = (a0 + b0) / 2.0f;
+    jy = (a1 + b1) / 2.0f;
+    (void)rng(s);      // tau_target slot of raymarch.glsl:28
+    off = rng(s);      // start jitter, raymarch.glsl:30
+  }
   Ray ray = setup_world_ray(p, tex_x, tex_y, jx, jy);
   DvrRay r;
   float near;
@@ -35,8 +37,29 @@ VXD DvrRay dvr_setup(const VxParams& p, int px, int py, uint32_t frame) {
   to_index(p, ray, r.ipos, r.idir);
   r.dt = p.dvr_step_voxels / sqrtf(dot3(r.idir, r.idir));
   r.t0 = fma_(off, r.dt, near);
-  r.env = p.show_environment > 0 ? lookup_environment(p, ray.d) : 0.0f;
+  r.wdir = ray.d;
   return r;
+}
+
+// write-back shared by the tuned DVR kernels: gain, background, sanitize, running mean
+VXD void dvr_store(const VxParams& p, const DvrRay& r, float Cx, float Cy, float Cz, float T,
+                   float weight, float4* __restrict__ slab, uint32_t si) {
+  float Lx = Cx * p.dvr_gain[0], Ly = Cy * p.dvr_gain[1], Lz = Cz * p.dvr_gain[2];
+  if (p.show_environment > 0 && T > 0.0f) {
+    float env = lookup_environment(p, r.wdir);
+    Lx = fma_(T, env, Lx);
+    Ly = fma_(T, env, Ly);
+    Lz = fma_(T, env, Lz);
+  }
+  Lx = sanitize1(Lx); Ly = sanitize1(Ly); Lz = sanitize1(Lz);
+  float4 prev = make_float4(0.f, 0.f, 0.f, 0.f);
+  if (weight != 0.0f) prev = slab[si];
+  float4 o;
+  o.x = fma_(1.0f - weight, Lx, weight * prev.x);
+  o.y = fma_(1.0f - weight, Ly, weight * prev.y);
+  o.z = fma_(1.0f - weight, Lz, weight * prev.z);
+  o.w = 1.0f;
+  slab[si] = o;
 }
 
 __global__ __launch_bounds__(256) void render_dvr_cq(const VxParams p, const DevVolume v,
@@ -132,30 +155,9 @@ __global__ __launch_bounds__(256) void render_dvr_cq(const VxParams p, const Dev
     ++k;
   }
 
-  if (in_image) {
-    float Lx = Cx * p.dvr_gain[0], Ly = Cy * p.dvr_gain[1], Lz = Cz * p.dvr_gain[2];
-    if (p.show_environment > 0 && T > 0.0f) {
-      Lx = fma_(T, r.env, Lx);
-      Ly = fma_(T, r.env, Ly);
-      Lz = fma_(T, r.env, Lz);
-    }
-    Lx = sanitize1(Lx); Ly = sanitize1(Ly); Lz = sanitize1(Lz);
-    float4 prev = make_float4(0.f, 0.f, 0.f, 0.f);
-    if (weight != 0.0f) prev = slab[si];
-    float4 o;
-    o.x = fma_(1.0f - weight, Lx, weight * prev.x);
-    o.y = fma_(1.0f - weight, Ly, weight * prev.y);
-    o.z = fma_(1.0f - weight, Lz, weight * prev.z);
-    o.w = 1.0f;
-    slab[si] = o;
-  }
+  if (in_image) dvr_store(p, r, Cx, Cy, Cz, T, weight, slab, si);
   const uint32_t n_px = (uint32_t)__builtin_popcountll(__ballot(in_image));
-  if (lane == 0) {
-    if (n_samples) atomicAdd(&dc->samples, (unsigned long long)n_samples);
-    if (n_rays) atomicAdd(&dc->rays, (unsigned long long)n_rays);
-    if (n_px) atomicAdd(&dc->pixels, (unsigned long long)n_px);
-    if (n_slots) atomicAdd(&dc->slots, (unsigned long long)n_slots);
-  }
+  add_counts(dc, n_samples, n_rays, n_px, 0u, 0u, n_slots);
 }
 
 inline void launch_dvr_cq(const VxParams& p, const DevVolume& v, const float4* tf, uint32_t tf_len,
