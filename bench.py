@@ -86,7 +86,7 @@ def main():
     ap.add_argument("--height", type=int, default=1080)
     ap.add_argument("--volume", type=int, default=512)
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--layout", type=int, default=None, help="0 reference, 1 cellquad, 2 brickf32 + LDS tiles (default)")
+    ap.add_argument("--layout", type=int, default=None, help="0 reference, 1 cellquad (default), 2 brickf32 + LDS tiles")
     a = ap.parse_args()
 
     import torch
@@ -179,7 +179,7 @@ def main():
                             "ERT eps 1e-4, clip box (0.25,0,0)-(1,1,0.75)",
                 "parallelism": f"image-tiles x{world} (64x64 tiles round-robin, volume replicated, "
                                "RCCL all_gather of the framebuffer per frame)" if world > 1 else "1 GPU",
-                "layout": {None: "brickf32", 0: "reference", 1: "cellquad", 2: "brickf32"}[a.layout],
+                "layout": {None: "cellquad", 0: "reference", 1: "cellquad", 2: "brickf32"}[a.layout],
                 "samples_per_frame": int(samples // a.steps),
                 "lane_utilisation": round(c.samples / slots, 4) if slots else None,
                 "device": name, "cus": cus, **info,
@@ -187,7 +187,7 @@ def main():
             "roofline": {
                 "bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                 "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": None,
-                "kernel": {None: "vx::render_dvr_tile<8>", 0: "vx::render_generic<3,0>", 1: "vx::render_dvr_cq", 2: "vx::render_dvr_tile<8>"}[a.layout],
+                "kernel": {None: "vx::render_dvr_cq<4>", 0: "vx::render_generic<3,0>", 1: "vx::render_dvr_cq<4>", 2: "vx::render_dvr_tile<8>"}[a.layout],
                 "avg_kernel_ms": round(c.kernel_ms / launches, 4),
                 "algorithmic_bytes_per_launch": int(alg_bytes_launch),
                 "rank0_gsamples_per_s_kernel_only": round(c.samples / (c.kernel_ms / 1e3) / 1e9, 3) if c.kernel_ms else None,

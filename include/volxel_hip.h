@@ -47,11 +47,12 @@ enum VxRenderMode {
 /* device layout of the brick grid used by the trilinear modes */
 enum VxLayout {
   VX_LAYOUT_REFERENCE = 0, /* the three reference textures, linear buffers (common.glsl:35-43) */
-  VX_LAYOUT_CELLQUAD = 1,  /* MI355X native: apron bricks of pre-decoded fp32 xy-quads, two
-                              16-byte gathers per sample straight from L1/L2              */
-  VX_LAYOUT_BRICKF32 = 2   /* MI355X native (default): 8^3 bricks decoded to fp32, 2 KiB
-                              contiguous each; the DVR kernel stages the active tile of
-                              voxels per wave through LDS                                 */
+  VX_LAYOUT_CELLQUAD = 1,  /* MI355X native (default): apron bricks of pre-decoded fp32
+                              xy-quads, two 16-byte gathers per sample, batches of 4 steps
+                              in flight per wave                                          */
+  VX_LAYOUT_BRICKF32 = 2   /* MI355X native: 8^3 bricks decoded to fp32, 2 KiB contiguous each;
+                              the DVR kernel stages the active tile of voxels per wave
+                              through LDS (4x less memory than cellquad, currently slower) */
 };
 
 /*
@@ -157,7 +158,7 @@ int vx_upload_volume(VxContext* ctx,
                      int n_mips, const uint16_t* const* mip_data, const uint32_t (*mip_size)[3],
                      const uint32_t index_extent[3]);
 
-/* select the device layout the trilinear modes sample from (default VX_LAYOUT_BRICKF32);
+/* select the device layout the trilinear modes sample from (default VX_LAYOUT_CELLQUAD);
  * takes effect at the next vx_upload_volume or immediately if a volume is resident. */
 int vx_set_layout(VxContext* ctx, int layout);
 

@@ -36,7 +36,7 @@ struct VxContext {
   std::vector<void*> vol_allocs;
   void* cq_alloc = nullptr;
   void* bf_alloc = nullptr;
-  int layout = VX_LAYOUT_BRICKF32;
+  int layout = VX_LAYOUT_CELLQUAD;
 
   // transfer function
   float4* tf = nullptr;

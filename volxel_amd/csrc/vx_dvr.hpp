@@ -7,6 +7,8 @@
 // wave-uniform ballot to skip the compositing block while no lane sees opacity, exact
 // per-wave sample counting with s_bcnt1 on the exec mask.
 #pragma once
+#include <cstdlib>
+
 #include "vx_kernels.hpp"
 
 namespace vx {
@@ -62,6 +64,10 @@ VXD void dvr_store(const VxParams& p, const DvrRay& r, float Cx, float Cy, float
   slab[si] = o;
 }
 
+// U = march steps per loop iteration: the 2*U gathers of a batch are issued back to back before
+// any of them is consumed, so a wave keeps 2*U loads in flight instead of 2 (the march is
+// latency-bound on the longest rays: tools/tail_probe.py).
+template <int U>
 __global__ __launch_bounds__(256) void render_dvr_cq(const VxParams p, const DevVolume v,
                                                       const float4* __restrict__ tf_global,
                                                       uint32_t tf_len, float4* __restrict__ slab,
@@ -97,62 +103,79 @@ __global__ __launch_bounds__(256) void render_dvr_cq(const VxParams p, const Dev
   uint32_t n_samples = 0, n_slots = 0;  // wave-uniform
 
   while (true) {
-    float t = fma_(kf, r.dt, r.t0);
-    alive = alive && (t < r.far) && (k < max_steps);
-    unsigned long long m = __ballot(alive);
-    if (m == 0ull) break;
-    n_samples += (uint32_t)__builtin_popcountll(m);
-    n_slots += 64u;
-    if (alive) {
+    {
+      float t = fma_(kf, r.dt, r.t0);
+      alive = alive && (t < r.far) && (k < max_steps);
+      if (__ballot(alive) == 0ull) break;
+    }
+    // ---- phase 1: addresses + gathers of U consecutive steps --------------------------------
+    float4 q0[U], q1[U];
+    float fx[U], fy[U], fz[U];
+    bool ok[U];
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      float t = fma_(kf + (float)u, r.dt, r.t0);
+      ok[u] = alive && (t < r.far) && (k + u < max_steps);
       // A5 on the cellquad layout: cell (floor(p-0.5)) + 1 -> apron brick / local cell
       float qx = fma_(t, r.idir.x, r.ipos.x) - 0.5f;
       float qy = fma_(t, r.idir.y, r.ipos.y) - 0.5f;
       float qz = fma_(t, r.idir.z, r.ipos.z) - 0.5f;
       float flx = floorf(qx), fly = floorf(qy), flz = floorf(qz);
-      float fx = qx - flx, fy = qy - fly, fz = qz - flz;
+      fx[u] = qx - flx; fy[u] = qy - fly; fz[u] = qz - flz;
       uint32_t cx = (uint32_t)((int)flx + 1), cy = (uint32_t)((int)fly + 1), cz = (uint32_t)((int)flz + 1);
-      // inside the clipped AABB these are always in the lattice; the clamp only makes a
-      // numerically stray ray read defined memory instead of faulting
+      // inside the clipped AABB these are always in the lattice; the clamp only makes a stray or
+      // already finished ray read defined memory instead of faulting
       cx = cx < cmaxx ? cx : cmaxx; cy = cy < cmaxy ? cy : cmaxy; cz = cz < cmaxz ? cz : cmaxz;
       uint32_t b = ((cz >> 3) * cby + (cy >> 3)) * cbx + (cx >> 3);
       uint32_t cell = ((cz & 7u) << 6) | ((cy & 7u) << 3) | (cx & 7u);
-      const float4* qp = cq + ((size_t)b * CQ_BRICK_QUADS + cell);
-      float4 q0 = qp[0];
-      float4 q1 = qp[CQ_SLICE_QUADS];
-      float wx = 1.0f - fx, wy = 1.0f - fy, wz = 1.0f - fz;
-      float lx0 = fma_(q0.y, fx, q0.x * wx);
-      float lx1 = fma_(q0.w, fx, q0.z * wx);
-      float hx0 = fma_(q1.y, fx, q1.x * wx);
-      float hx1 = fma_(q1.w, fx, q1.z * wx);
-      float l = fma_(lx1, fy, lx0 * wy);
-      float h = fma_(hx1, fy, hx0 * wy);
-      float d = scale * fma_(h, fz, l * wz);
-      float dn = d * inv_maj;
-      // A7: NEAREST LUT, range test
-      int ti = (int)(dn * lenf);  // dn >= 0: truncation == floor
-      ti = ti > last ? last : ti;
-      ti = ti < 0 ? 0 : ti;
-      bool in_range = !(dn < sr0 || dn > sr1);
-      float4 rgba = tf_lds[ti];
-      float alpha = in_range ? rgba.w : 0.0f;
-      if (__ballot(alpha > 0.0f) != 0ull) {
-        // tau += a*maj*dt; C += (T_prev - T) * rgb   (raymarch.glsl:43 / SURVEY A12)
-        tau = fma_(alpha * maj, r.dt, tau);
-        float Tn = __builtin_amdgcn_exp2f(tau * -1.4426950408889634f);
-        Tn = alpha > 0.0f ? Tn : T;
-        float dT = T - Tn;
-        Cx = fma_(dT, rgba.x, Cx);
-        Cy = fma_(dT, rgba.y, Cy);
-        Cz = fma_(dT, rgba.z, Cz);
-        T = Tn;
-        if (tau >= ert) {
-          T = 0.0f;
-          alive = false;
+      // unconditional loads (finished lanes read quad 0): no control flow between the 2*U
+      // gathers, so they are all in flight before the first s_waitcnt
+      size_t o = ok[u] ? ((size_t)b * CQ_BRICK_QUADS + cell) : (size_t)0;
+      q0[u] = cq[o];
+      q1[u] = cq[o + CQ_SLICE_QUADS];
+    }
+    // ---- phase 2: interpolate, classify, composite in order -----------------------------------
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      bool a = ok[u] && alive;  // a lane that terminated earlier in this batch drops out
+      unsigned long long m = __ballot(a);
+      n_samples += (uint32_t)__builtin_popcountll(m);
+      n_slots += m ? 64u : 0u;
+      if (a) {
+        float wx = 1.0f - fx[u], wy = 1.0f - fy[u], wz = 1.0f - fz[u];
+        float lx0 = fma_(q0[u].y, fx[u], q0[u].x * wx);
+        float lx1 = fma_(q0[u].w, fx[u], q0[u].z * wx);
+        float hx0 = fma_(q1[u].y, fx[u], q1[u].x * wx);
+        float hx1 = fma_(q1[u].w, fx[u], q1[u].z * wx);
+        float l = fma_(lx1, fy[u], lx0 * wy);
+        float h = fma_(hx1, fy[u], hx0 * wy);
+        float d = scale * fma_(h, fz[u], l * wz);
+        float dn = d * inv_maj;
+        // A7: NEAREST LUT, range test
+        int ti = (int)(dn * lenf);  // dn >= 0: truncation == floor
+        ti = ti > last ? last : ti;
+        ti = ti < 0 ? 0 : ti;
+        bool in_range = !(dn < sr0 || dn > sr1);
+        float4 rgba = tf_lds[ti];
+        float alpha = in_range ? rgba.w : 0.0f;
+        if (alpha > 0.0f) {
+          // tau += a*maj*dt; C += (T_prev - T) * rgb   (raymarch.glsl:43 / SURVEY A12)
+          tau = fma_(alpha * maj, r.dt, tau);
+          float Tn = __builtin_amdgcn_exp2f(tau * -1.4426950408889634f);
+          float dT = T - Tn;
+          Cx = fma_(dT, rgba.x, Cx);
+          Cy = fma_(dT, rgba.y, Cy);
+          Cz = fma_(dT, rgba.z, Cz);
+          T = Tn;
+          if (tau >= ert) {
+            T = 0.0f;
+            alive = false;
+          }
         }
       }
     }
-    kf += 1.0f;
-    ++k;
+    kf += (float)U;
+    k += U;
   }
 
   if (in_image) dvr_store(p, r, Cx, Cy, Cz, T, weight, slab, si);
@@ -164,8 +187,15 @@ inline void launch_dvr_cq(const VxParams& p, const DevVolume& v, const float4* t
                           float4* slab, uint32_t frame, float weight, const TileMap& tm,
                           DevCounters* dc, hipStream_t stream, int /*n_cus*/) {
   uint32_t groups = (tm.tiles_per_shard + 7u) / 8u;
-  hipLaunchKernelGGL(render_dvr_cq, dim3(groups * 128u), dim3(256), (size_t)tf_len * sizeof(float4),
-                     stream, p, v, tf, tf_len, slab, frame, weight, tm, dc);
+  static const int unroll = [] { const char* e = getenv("VX_DVR_UNROLL"); return e ? atoi(e) : 4; }();
+  dim3 grid(groups * 128u), block(256);
+  size_t lds = (size_t)tf_len * sizeof(float4);
+  switch (unroll) {
+    case 1: hipLaunchKernelGGL(render_dvr_cq<1>, grid, block, lds, stream, p, v, tf, tf_len, slab, frame, weight, tm, dc); break;
+    case 2: hipLaunchKernelGGL(render_dvr_cq<2>, grid, block, lds, stream, p, v, tf, tf_len, slab, frame, weight, tm, dc); break;
+    case 8: hipLaunchKernelGGL(render_dvr_cq<8>, grid, block, lds, stream, p, v, tf, tf_len, slab, frame, weight, tm, dc); break;
+    default: hipLaunchKernelGGL(render_dvr_cq<4>, grid, block, lds, stream, p, v, tf, tf_len, slab, frame, weight, tm, dc); break;
+  }
 }
 
 }  // namespace vx
