@@ -1,0 +1,75 @@
+"""The Node N-API shim + JavaScript host (volxel_amd/napi): loads under the image's Node 12,
+exports the boundary, its brick builder output equals the oracle's, it refuses to run without a
+GPU (CPU test), and one DVR frame rendered from JavaScript matches the oracle (GPU test)."""
+import ctypes as C
+import json
+import os
+import shutil
+import subprocess
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+NAPI = os.path.join(ROOT, "volxel_amd", "napi")
+
+pytestmark = pytest.mark.skipif(shutil.which("node") is None, reason="node not installed")
+
+
+def _build():
+    subprocess.check_call(["make", "-C", os.path.join(ROOT, "volxel_amd", "csrc"), "-s"])
+    subprocess.check_call(["make", "-C", NAPI, "-s"])
+
+
+def _run(tmp_path, *extra):
+    _build()
+    subprocess.check_call(["node", os.path.join(NAPI, "smoke.js"), str(tmp_path), *extra], timeout=300)
+
+
+def _check_grid(oracle, tmp_path):
+    from volxel_amd import synth
+    vox, sp = synth.sphere(32)
+    g = oracle.BrickGrid(vox, sp)
+    meta = json.load(open(tmp_path / "meta.json"))
+    assert tuple(meta["atlasSize"]) == g.atlas_size and tuple(meta["indexExtent"]) == g.index_extent
+    assert meta["brickCounter"] == g.brick_counter
+    assert np.array_equal(np.fromfile(tmp_path / "atlas.bin", dtype=np.uint8), g.atlas)
+    assert np.array_equal(np.fromfile(tmp_path / "indirection.bin", dtype=np.uint32), g.indirection)
+    assert np.array_equal(np.fromfile(tmp_path / "range.bin", dtype=np.uint16), g.range)
+    from volxel_amd import default_transfer_function
+    assert np.array_equal(np.fromfile(tmp_path / "tf.bin", dtype=np.float32), default_transfer_function()[0])
+    return g
+
+
+def test_node_host_cpu(oracle, tmp_path):
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("GPU present: covered by the gpu test")
+    _run(tmp_path)
+    _check_grid(oracle, tmp_path)
+    assert json.load(open(tmp_path / "nogpu.json"))["threw"] is True   # no JavaScript/CPU fallback
+    keys = subprocess.check_output(["node", "-e", "console.log(Object.keys(require('%s')).join(','))" % NAPI]).decode()
+    for k in ("Volxel3DDicomRenderer", "VolxelRenderMode", "generateTransferFunction"):
+        assert k in keys
+
+
+@pytest.mark.gpu
+def test_node_host_renders_like_the_oracle(oracle, tmp_path):
+    _run(tmp_path, "gpu")
+    g = _check_grid(oracle, tmp_path)
+    p = oracle.VxParams()
+    raw = open(tmp_path / "params.bin", "rb").read()
+    assert len(raw) == C.sizeof(p)
+    C.memmove(C.byref(p), raw, len(raw))
+    from volxel_amd import default_transfer_function
+    tf, L = default_transfer_function()
+    want, oc = oracle.render(p, g, tf, L)
+    img = np.fromfile(tmp_path / "accum.bin", dtype=np.float32).reshape(p.res[1], p.res[0], 4)
+    assert np.abs(img - want).max() <= 2e-6
+    assert json.load(open(tmp_path / "counters.json"))["samples"] == oc.samples
+    # the JS host's uniforms agree with the Python host's (both restate viewer.ts:1295-1357)
+    from tests.common import make_scene
+    s, cam, vol, ds, pp = make_scene(g, p.res[0], p.res[1], "dvr")
+    a = np.frombuffer(raw, dtype=np.float32)
+    b = np.frombuffer(bytes(pp), dtype=np.float32)
+    assert np.allclose(a[:140], b[:140], rtol=1e-6, atol=1e-7)

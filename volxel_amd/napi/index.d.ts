@@ -1,0 +1,31 @@
+// Typings of the headless host (names follow volxel-3d-viewer/src/viewer.ts, utils/data.ts, common.ts)
+export type ColorStop = { color: [number, number, number, number]; stop: number };
+export type BrickGridMessage = {            // WasmWorkerMessageDicomReturn, common.ts:37-55
+  type: "return_dicom";
+  indirectionSize: [number, number, number]; rangeSize: [number, number, number]; atlasSize: [number, number, number];
+  transform: Float32Array; histogram: Uint32Array; histogramGradientRange: [number, number];
+  histogramGradient: Int32Array; minMaj: [number, number]; indexExtent: [number, number, number];
+  rangeMipmaps: { mipmap: Uint16Array; stride: [number, number, number] }[];
+  indirection: Uint32Array; range: Uint16Array; atlas: Uint8Array; brickCounter: number;
+};
+export declare const VolxelRenderMode: { default: 0; no_dda: 1; raymarch: 2; dvr: 3; dvr_phong: 4 };
+export declare function generateTransferFunction(colors: ColorStop[], generatedSteps?: number): { data: Float32Array; length: number };
+export declare class Camera { pos: number[]; view: number[]; constructor(distance?: number); viewMatrix(): number[]; projMatrix(aspect: number, fov?: number): number[]; }
+export declare class Volxel3DDicomRenderer {
+  constructor(opts?: { width?: number; height?: number; device?: number; layout?: number });
+  settings: Record<string, any>; camera: Camera; envStrength: number; frameIndex: number;
+  renderMode: keyof typeof VolxelRenderMode;
+  restartFromVoxels(voxels: Uint16Array, dims: [number, number, number], spacing?: [number, number, number], maxValue?: number, threads?: number): void;
+  setupFromGrid(grid: BrickGridMessage): void;
+  changeTransferFunc(data: Float32Array, length: number): void;
+  restartRendering(): void;
+  restoreSettings(settings: any): void;
+  bindUniforms(): { buffer: ArrayBuffer };
+  render(frames?: number): void;
+  finish(): void;
+  readAccum(): Float32Array;
+  readDisplay(): Uint8Array;
+  counters(): { samples: number; rays: number; pixels: number; skipSteps: number; gradSamples: number; laneSlots: number; launches: number; kernelMs: number; lastKernelMs: number };
+  resetCounters(): void;
+  dispose(): void;
+}

@@ -1,0 +1,35 @@
+'use strict';
+// node smoke.js <out_dir> [gpu]: brick builder through N-API (CPU); with "gpu" also one DVR frame.
+const fs = require('fs');
+const path = require('path');
+const { Volxel3DDicomRenderer, generateTransferFunction, native } = require('./index');
+const out = process.argv[2];
+const n = 32;
+const vox = new Uint16Array(n * n * n);
+for (let z = 0; z < n; ++z) for (let y = 0; y < n; ++y) for (let x = 0; x < n; ++x) {
+  const c = (n - 1) / 2, r = 28 * n / 64;
+  const d = Math.sqrt((x - c) ** 2 + (y - c) ** 2 + (z - c) ** 2);
+  vox[(z * n + y) * n + x] = Math.round(4095 * Math.max(0, 1 - d / r));
+}
+const grid = native.buildBrickGrid(vox, [n, n, n], [1, 1, 1], 0, 2);
+fs.writeFileSync(path.join(out, 'atlas.bin'), Buffer.from(grid.atlas.buffer));
+fs.writeFileSync(path.join(out, 'indirection.bin'), Buffer.from(grid.indirection.buffer));
+fs.writeFileSync(path.join(out, 'range.bin'), Buffer.from(grid.range.buffer));
+fs.writeFileSync(path.join(out, 'meta.json'), JSON.stringify({ atlasSize: grid.atlasSize, indexExtent: grid.indexExtent,
+  brickCounter: grid.brickCounter, minMaj: grid.minMaj, mips: grid.rangeMipmaps.map(m => m.stride) }));
+const tf = generateTransferFunction([{ color: [1, 1, 1, 0], stop: 0 }, { color: [1, 1, 1, 1], stop: 1 }]);
+fs.writeFileSync(path.join(out, 'tf.bin'), Buffer.from(tf.data.buffer));
+if (process.argv[3] === 'gpu') {
+  const r = new Volxel3DDicomRenderer({ width: 96, height: 64 });
+  r.setupFromGrid(grid);
+  r.settings.renderMode = 'dvr'; r.settings.bounces = 1;
+  r.render(1);
+  fs.writeFileSync(path.join(out, 'accum.bin'), Buffer.from(r.readAccum().buffer));
+  fs.writeFileSync(path.join(out, 'params.bin'), Buffer.from(r.params.buffer));
+  fs.writeFileSync(path.join(out, 'counters.json'), JSON.stringify(r.counters()));
+  r.dispose();
+} else {
+  let threw = false;
+  try { new Volxel3DDicomRenderer({ width: 8, height: 8 }); } catch (e) { threw = /no HIP device|failed/.test(e.message); }
+  fs.writeFileSync(path.join(out, 'nogpu.json'), JSON.stringify({ threw }));
+}

@@ -1,0 +1,263 @@
+'use strict';
+/**
+ * Headless JavaScript host over the N-API shim: keeps the public surface of the reference's
+ * render core (class Volxel3DDicomRenderer, volxel-3d-viewer/src/viewer.ts) for the calls on
+ * the hot path -- setupFromGrid (viewer.ts:1080-1145), changeTransferFunc (:1147-1153),
+ * restartRendering (:1155-1181), bindUniforms (:1295-1357), render (:1183-1293), renderMode
+ * (:1442-1452), restoreSettings (:704-713) -- and of utils/data.ts (generateTransferFunction).
+ * The reference is TypeScript + math.gl in a browser; the build image has Node 12 without tsc,
+ * so this is plain ES2019 with the typings in index.d.ts.  Everything that touches pixels goes
+ * through libvolxel_hip.so; there is no JavaScript fallback.
+ */
+const fs = require('fs');
+const path = require('path');
+const native = require('./volxel_napi.node');
+
+const RenderMode = Object.freeze({ default: 0, no_dda: 1, raymarch: 2, dvr: 3, dvr_phong: 4 });
+const LOW_RES_DURATION = 5; // viewer.ts:132
+
+// ---- VxParams field table, parsed from the C header (single source of truth) --------------
+function parseParamsLayout() {
+  const text = fs.readFileSync(path.join(__dirname, '..', '..', 'include', 'volxel_hip.h'), 'utf8')
+    .replace(/\/\*[\s\S]*?\*\//g, '');
+  const body = /typedef\s+struct\s+VxParams\s*\{([\s\S]*?)\}\s*VxParams\s*;/.exec(text)[1];
+  const fields = {};
+  let off = 0;
+  for (const decl of body.split(';')) {
+    const m = /^\s*(\w+)\s+([\s\S]+)$/.exec(decl);
+    if (!m) continue;
+    for (const item of m[2].split(',')) {
+      const a = /^\s*(\w+)\s*(?:\[(\d+)\])?\s*$/.exec(item);
+      const n = a[2] ? parseInt(a[2], 10) : 1;
+      fields[a[1]] = { type: m[1], offset: off, count: n };
+      off += 4 * n;
+    }
+  }
+  if (off !== native.sizeofParams()) throw new Error('VxParams layout mismatch between header and library');
+  return { fields, size: off };
+}
+const LAYOUT = parseParamsLayout();
+
+class ParamsBlock {
+  constructor() { this.buffer = new ArrayBuffer(LAYOUT.size); this.view = new DataView(this.buffer); }
+  set(name, value) {
+    const f = LAYOUT.fields[name];
+    if (!f) throw new Error(`unknown uniform ${name}`);
+    const vals = (typeof value === 'number') ? [value] : Array.from(value);
+    if (vals.length !== f.count) throw new Error(`uniform ${name} expects ${f.count} values`);
+    vals.forEach((v, i) => {
+      const o = f.offset + 4 * i;
+      if (f.type === 'float') this.view.setFloat32(o, v, true);
+      else if (f.type === 'uint32_t') this.view.setUint32(o, v, true);
+      else this.view.setInt32(o, v, true);
+    });
+  }
+}
+
+// ---- column-major 4x4 helpers in doubles (gl-matrix conventions used through math.gl) ------
+const M = {
+  identity: () => [1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1],
+  mul(a, b) { // a * b
+    const o = new Array(16).fill(0);
+    for (let c = 0; c < 4; ++c) for (let r = 0; r < 4; ++r)
+      for (let k = 0; k < 4; ++k) o[4 * c + r] += a[4 * k + r] * b[4 * c + k];
+    return o;
+  },
+  scale: (s) => [s[0], 0, 0, 0, 0, s[1], 0, 0, 0, 0, s[2], 0, 0, 0, 0, 1],
+  translate: (t) => [1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1, 0, t[0], t[1], t[2], 1],
+  apply(m, v) { return [0, 1, 2, 3].map(r => m[r] * v[0] + m[4 + r] * v[1] + m[8 + r] * v[2] + m[12 + r] * v[3]); },
+  lookAt(eye, center, up) { // scene.ts:58-64
+    let z = [eye[0] - center[0], eye[1] - center[1], eye[2] - center[2]];
+    if (z.every(c => Math.abs(c) < 1e-6)) return M.identity();
+    const n = (v) => { const l = Math.hypot(v[0], v[1], v[2]); return l ? v.map(c => c / l) : [0, 0, 0]; };
+    const cross = (a, b) => [a[1] * b[2] - a[2] * b[1], a[2] * b[0] - a[0] * b[2], a[0] * b[1] - a[1] * b[0]];
+    const dot = (a, b) => a[0] * b[0] + a[1] * b[1] + a[2] * b[2];
+    z = n(z);
+    const x = n(cross(up, z));
+    const y = n(cross(z, x));
+    return [x[0], y[0], z[0], 0, x[1], y[1], z[1], 0, x[2], y[2], z[2], 0, -dot(x, eye), -dot(y, eye), -dot(z, eye), 1];
+  },
+  perspective(fovy, aspect, near, far) { // scene.ts:65-72
+    const f = 1 / Math.tan(fovy / 2), nf = 1 / (near - far);
+    return [f / aspect, 0, 0, 0, 0, f, 0, 0, 0, 0, (far + near) * nf, -1, 0, 0, 2 * far * near * nf, 0];
+  },
+  invert(m) { // Gauss-Jordan with partial pivoting on the 4x4
+    const a = [0, 1, 2, 3].map(r => [m[r], m[4 + r], m[8 + r], m[12 + r], +(r === 0), +(r === 1), +(r === 2), +(r === 3)]);
+    for (let c = 0; c < 4; ++c) {
+      let p = c;
+      for (let r = c + 1; r < 4; ++r) if (Math.abs(a[r][c]) > Math.abs(a[p][c])) p = r;
+      if (a[p][c] === 0) throw new Error('singular matrix');
+      [a[c], a[p]] = [a[p], a[c]];
+      const d = a[c][c];
+      for (let k = 0; k < 8; ++k) a[c][k] /= d;
+      for (let r = 0; r < 4; ++r) if (r !== c) { const f = a[r][c]; for (let k = 0; k < 8; ++k) a[r][k] -= f * a[c][k]; }
+    }
+    const o = new Array(16);
+    for (let r = 0; r < 4; ++r) for (let c = 0; c < 4; ++c) o[4 * c + r] = a[r][4 + c];
+    return o;
+  },
+  f32: (m) => Array.from(new Float32Array(m)),
+};
+
+// ---- utils/data.ts:21-60 ---------------------------------------------------------------
+function generateTransferFunction(colors, generatedSteps = 128) {
+  if (colors.length < 1) throw new Error('At least one color stop required');
+  const stops = colors.slice().sort((a, b) => a.stop - b.stop);
+  if (stops.some(s => s.stop < 0 || s.stop > 1)) throw new Error('ColorStop outside stop range');
+  const out = [];
+  let cur = -1;
+  for (let i = 0; i < generatedSteps; ++i) {
+    const pos = i / generatedSteps;
+    if (cur < 0) {
+      if (stops[0].stop >= pos) { cur = 0; out.push(stops[0].color); } else out.push([0, 0, 0, 0]);
+      continue;
+    }
+    const next = stops[cur + 1];
+    if (!next) { out.push(stops[cur].color); continue; }
+    const w = (pos - stops[cur].stop) / (next.stop - stops[cur].stop);
+    if (w >= 1) { out.push(next.color); cur++; continue; }
+    out.push(stops[cur].color.map((v, k) => (1 - w) * v + w * next.color[k]));
+  }
+  return { data: new Float32Array(out.flat()), length: generatedSteps };
+}
+
+class Camera { // representation/scene.ts
+  constructor(distance = 1) { this.view = [0, 0, 0]; this.pos = [0, 0, -distance]; }
+  viewMatrix() { return M.lookAt(this.pos, this.view, [0, 1, 0]); }
+  projMatrix(aspect, fov = Math.PI / 3) { return M.perspective(fov, aspect, 0.1, 1000); }
+}
+
+class Volxel3DDicomRenderer {
+  constructor({ width = 1920, height = 1080, device = 0, layout } = {}) {
+    this.ctx = native.create(device);            // throws when no GPU is visible
+    this.width = width; this.height = height;
+    this.settings = { // viewer.ts:147-163 + [build] DVR parameters
+      densityMultiplier: 1, maxSamples: 2000, debugHits: false, volumeClipMin: [0, 0, 0], volumeClipMax: [1, 1, 1],
+      showEnvironment: true, useEnv: true, lightDir: [-1, -1, -1].map(v => v / Math.sqrt(3)), syncLightDir: false,
+      bounces: 3, gamma: 2.2, exposure: 5.5, sampleRange: [0, 1], renderMode: 'default', resolutionFactor: 1,
+      dvrStepVoxels: 0.5, dvrErtEpsilon: 1e-4, dvrJitter: false, dvrMaxSteps: 1 << 20, phong: [0.3, 0.7, 0.4, 32],
+    };
+    this.camera = new Camera(1);                  // viewer.ts:418
+    this.envStrength = 1;
+    this.frameIndex = 0;
+    this.densityScale = 1;
+    this.volume = null;
+    if (layout !== undefined) native.setLayout(this.ctx, layout);
+    native.resize(this.ctx, width, height);
+    const tf = generateTransferFunction([{ color: [1, 1, 1, 0], stop: 0 }, { color: [1, 1, 1, 1], stop: 1 }]);
+    this.changeTransferFunc(tf.data, tf.length);  // viewer.ts:377-385
+  }
+  dispose() { if (this.ctx) { native.destroy(this.ctx); this.ctx = null; } }
+
+  get renderMode() { return this.settings.renderMode; }
+  set renderMode(to) {
+    if (!(to in RenderMode)) throw new Error(`Unrecognized render mode provided: ${to}`);
+    this.settings.renderMode = to; this.restartRendering();
+  }
+
+  /** replaces restartFromFiles/Zip/URLs for an already decoded u16 stack (DICOM I/O is row N1) */
+  restartFromVoxels(voxels, dims, spacing = [1, 1, 1], maxValue = 0, threads = 0) {
+    this.setupFromGrid(native.buildBrickGrid(voxels, dims, spacing, maxValue, threads));
+  }
+
+  setupFromGrid(grid) { // viewer.ts:1080-1145
+    this.densityScale = 1;
+    this.settings.volumeClipMax = [1, 1, 1]; this.settings.volumeClipMin = [0, 0, 0];
+    const g = Array.from(grid.transform);
+    const e = grid.indexExtent;
+    const lo = M.apply(g, [0, 0, 0, 1]).slice(0, 3), hi = M.apply(g, [e[0], e[1], e[2], 1]).slice(0, 3);
+    const ext = hi.map((v, i) => v - lo[i]);
+    const size = Math.max(ext[0], Math.max(ext[1], ext[2]));
+    let t = M.identity();
+    if (size !== 1) {
+      t = M.mul(M.scale([1 / size, 1 / size, 1 / size]), M.translate(lo.map((v, i) => -v - ext[i] * 0.5)));
+      this.densityScale *= size;
+    }
+    this.volume = { grid: { transform: g, indexExtent: e, minMaj: grid.minMaj }, transform: t };
+    native.uploadVolume(this.ctx, grid);
+    this.restartRendering();
+  }
+
+  changeTransferFunc(data, length) { // viewer.ts:1147-1153
+    native.uploadTransfer(this.ctx, data, length);
+    this.frameIndex = 0;
+  }
+  restartRendering() { this.frameIndex = 0; }   // viewer.ts:1155-1181
+
+  restoreSettings(s) { // viewer.ts:704-713 (+ transfer/display/lighting closures)
+    if (s.version !== 'v3') throw new Error(`Unsupported Settings Format Version: ${s.version}`);
+    this.settings.densityMultiplier = s.transfer.densityMultiplier;
+    this.settings.sampleRange = s.transfer.histogramRange.slice();
+    if (s.transfer.transfer.type === 'color_stops') {
+      const tf = generateTransferFunction(s.transfer.transfer.colors);
+      this.changeTransferFunc(tf.data, tf.length);
+    } else {
+      this.changeTransferFunc(new Float32Array(s.transfer.transfer.colors.flat()), s.transfer.transfer.colors.length);
+    }
+    Object.assign(this.settings, {
+      bounces: s.display.bounces, maxSamples: s.display.samples, gamma: s.display.gamma, exposure: s.display.exposure,
+      debugHits: s.display.debugHits, renderMode: s.display.renderMode, resolutionFactor: s.display.resolutionFactor,
+      showEnvironment: s.lighting.showEnv, useEnv: s.lighting.useEnv, syncLightDir: s.lighting.syncLightDir,
+      lightDir: s.lighting.lightDir.slice(), volumeClipMax: s.other.clipMax.slice(), volumeClipMin: s.other.clipMin.slice(),
+    });
+    this.envStrength = s.lighting.envStrength;
+    this.camera.pos = s.other.cameraPos.slice(); this.camera.view = s.other.cameraLookAt.slice();
+    this.restartRendering();
+  }
+
+  bindUniforms() { // viewer.ts:1295-1357 + scene.ts:53-56
+    if (!this.volume) throw new Error('Trying to bind uniforms without a volume.');
+    const p = new ParamsBlock(), s = this.settings;
+    const view = this.camera.viewMatrix(), proj = this.camera.projMatrix(this.width / this.height);
+    p.set('camera_view', view); p.set('camera_proj', proj);
+    p.set('camera_view_inv', M.invert(M.f32(view))); p.set('camera_proj_inv', M.invert(M.f32(proj)));
+    const combined = M.mul(this.volume.transform, this.volume.grid.transform); // volume.ts:14-16
+    const e = this.volume.grid.indexExtent;
+    const lo = M.apply(combined, [0, 0, 0, 1]), hi = M.apply(combined, [e[0], e[1], e[2], 1]);
+    p.set('volume_aabb_min', [0, 1, 2].map(i => lo[i] + (hi[i] - lo[i]) * s.volumeClipMin[i]));
+    p.set('volume_aabb_max', [0, 1, 2].map(i => lo[i] + (hi[i] - lo[i]) * s.volumeClipMax[i]));
+    const [mn, maj] = this.volume.grid.minMaj, k = this.densityScale * s.densityMultiplier;
+    p.set('volume_min', mn * k); p.set('volume_maj', maj * k); p.set('volume_inv_maj', 1 / (maj * k));
+    p.set('volume_albedo', [0.9, 0.9, 0.9]); p.set('volume_phase_g', 0); p.set('volume_density_scale', k);
+    p.set('density_transform', combined); p.set('density_transform_inv', M.invert(combined));
+    p.set('sample_range', s.sampleRange);
+    p.set('light_dir', s.lightDir); p.set('env_strength', this.envStrength);
+    p.set('show_environment', s.showEnvironment ? 1 : 0); p.set('use_env', 0); p.set('bounces', s.bounces);
+    p.set('res', [this.width, this.height]); p.set('debug_hits', s.debugHits ? 1 : 0);
+    p.set('render_mode', RenderMode[s.renderMode]);
+    p.set('dvr_step_voxels', s.dvrStepVoxels); p.set('dvr_ert_tau', -Math.log(s.dvrErtEpsilon));
+    p.set('dvr_jitter', s.dvrJitter ? 1 : 0); p.set('dvr_max_steps', s.dvrMaxSteps);
+    const f = Math.fround;
+    const fp = f(f(1) / f(f(4) * f(Math.PI)));                         // utils.glsl:121-124, g = 0
+    const mis = s.showEnvironment ? f(f(1) / f(f(1) + f(fp * fp))) : f(1); // utils.glsl:104
+    const gain = f(f(f(f(0.9) * mis) * fp) * f(f(this.envStrength) * f(4.01)));
+    p.set('dvr_gain', [gain, gain, gain]);
+    p.set('phong_ka', s.phong[0]); p.set('phong_kd', s.phong[1]); p.set('phong_ks', s.phong[2]);
+    p.set('phong_shininess', s.phong[3]);
+    p.set('shard_rank', 0); p.set('shard_count', 1);
+    native.setParams(this.ctx, p.buffer);
+    this.params = p;
+    return p;
+  }
+
+  render(frames = 1) { // viewer.ts:1183-1293
+    this.bindUniforms();
+    for (let i = 0; i < frames && this.frameIndex <= this.settings.maxSamples; ++i) {
+      const f = this.frameIndex;
+      const w = f < LOW_RES_DURATION ? 0 : (f - LOW_RES_DURATION) / (f - LOW_RES_DURATION + 1); // viewer.ts:1356
+      native.renderFrame(this.ctx, f, w);
+      this.frameIndex++;
+    }
+  }
+  finish() { native.finish(this.ctx); }
+  readAccum() { const o = new Float32Array(this.width * this.height * 4); native.readAccum(this.ctx, o); return o; }
+  readDisplay() {
+    const o = new Uint8Array(this.width * this.height * 4);
+    native.readDisplay(this.ctx, o, this.settings.exposure, this.settings.gamma);
+    return o;
+  }
+  counters() { return native.getCounters(this.ctx); }
+  resetCounters() { native.resetCounters(this.ctx); }
+}
+
+module.exports = { Volxel3DDicomRenderer, VolxelRenderMode: RenderMode, generateTransferFunction, Camera, native };

@@ -1,0 +1,401 @@
+/*
+ * volxel_napi.c -- thin Node N-API shim over the C ABI of libvolxel_hip.so
+ * (include/volxel_hip.h, include/volxel_brick.h).  One JS function per C entry point;
+ * typed arrays are passed without copying; a non-zero status becomes a thrown JS Error
+ * carrying vx_last_error(), so the host's handleError contract (viewer.ts:797-816) holds.
+ * Plain C against <node_api.h> (N-API v3+, Node >= 10).
+ */
+#include <node_api.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+
+#include "../../include/volxel_brick.h"
+#include "../../include/volxel_hip.h"
+
+#define NAPI_OK(call)                                                    \
+  do {                                                                   \
+    if ((call) != napi_ok) {                                             \
+      napi_throw_error(env, NULL, "volxel_napi: N-API call failed: " #call); \
+      return NULL;                                                       \
+    }                                                                    \
+  } while (0)
+
+static napi_value throw_msg(napi_env env, const char* msg) {
+  napi_throw_error(env, NULL, msg && *msg ? msg : "volxel_hip: unknown error");
+  return NULL;
+}
+
+static int get_args(napi_env env, napi_callback_info info, size_t n, napi_value* argv) {
+  size_t argc = n;
+  if (napi_get_cb_info(env, info, &argc, argv, NULL, NULL) != napi_ok || argc < n) {
+    napi_throw_type_error(env, NULL, "volxel_napi: wrong number of arguments");
+    return 0;
+  }
+  return 1;
+}
+
+static VxContext* get_ctx(napi_env env, napi_value v) {
+  void* p = NULL;
+  if (napi_get_value_external(env, v, &p) != napi_ok || !p) {
+    napi_throw_type_error(env, NULL, "volxel_napi: expected a context handle");
+    return NULL;
+  }
+  return (VxContext*)p;
+}
+
+/* typed array -> pointer + element count (+ checks the element type) */
+static int typed(napi_env env, napi_value v, napi_typedarray_type want, void** data, size_t* len) {
+  napi_typedarray_type t;
+  napi_value ab;
+  size_t off;
+  if (napi_get_typedarray_info(env, v, &t, len, data, &ab, &off) != napi_ok || t != want) {
+    napi_throw_type_error(env, NULL, "volxel_napi: typed array of the wrong element type");
+    return 0;
+  }
+  return 1;
+}
+
+static int u32x3(napi_env env, napi_value arr, uint32_t out[3]) {
+  for (uint32_t i = 0; i < 3; ++i) {
+    napi_value e;
+    if (napi_get_element(env, arr, i, &e) != napi_ok || napi_get_value_uint32(env, e, &out[i]) != napi_ok) {
+      napi_throw_type_error(env, NULL, "volxel_napi: expected [x, y, z]");
+      return 0;
+    }
+  }
+  return 1;
+}
+
+static napi_value prop(napi_env env, napi_value obj, const char* name) {
+  napi_value v = NULL;
+  napi_get_named_property(env, obj, name, &v);
+  return v;
+}
+
+static void ctx_finalize(napi_env env, void* data, void* hint) {
+  (void)env; (void)hint;
+  /* contexts are destroyed explicitly (destroy()); nothing to do for a dangling handle */
+  (void)data;
+}
+
+/* create(deviceId) -> handle */
+static napi_value n_create(napi_env env, napi_callback_info info) {
+  napi_value a[1];
+  if (!get_args(env, info, 1, a)) return NULL;
+  int32_t dev = 0;
+  NAPI_OK(napi_get_value_int32(env, a[0], &dev));
+  VxContext* c = NULL;
+  if (vx_create(dev, &c) != VX_OK) return throw_msg(env, vx_last_error(NULL));
+  napi_value h;
+  NAPI_OK(napi_create_external(env, c, ctx_finalize, NULL, &h));
+  return h;
+}
+
+static napi_value n_destroy(napi_env env, napi_callback_info info) {
+  napi_value a[1];
+  if (!get_args(env, info, 1, a)) return NULL;
+  VxContext* c = get_ctx(env, a[0]);
+  if (c) vx_destroy(c);
+  return NULL;
+}
+
+/* uploadVolume(ctx, msg): msg = WasmWorkerMessageDicomReturn (common.ts:37-55) */
+static napi_value n_upload_volume(napi_env env, napi_callback_info info) {
+  napi_value a[2];
+  if (!get_args(env, info, 2, a)) return NULL;
+  VxContext* c = get_ctx(env, a[0]);
+  if (!c) return NULL;
+  napi_value m = a[1];
+  void *ind, *rng, *atl;
+  size_t n;
+  uint32_t is[3], rs[3], as[3], ext[3];
+  if (!typed(env, prop(env, m, "indirection"), napi_uint32_array, &ind, &n)) return NULL;
+  if (!typed(env, prop(env, m, "range"), napi_uint16_array, &rng, &n)) return NULL;
+  if (!typed(env, prop(env, m, "atlas"), napi_uint8_array, &atl, &n)) return NULL;
+  if (!u32x3(env, prop(env, m, "indirectionSize"), is) || !u32x3(env, prop(env, m, "rangeSize"), rs) ||
+      !u32x3(env, prop(env, m, "atlasSize"), as) || !u32x3(env, prop(env, m, "indexExtent"), ext))
+    return NULL;
+  napi_value mips = prop(env, m, "rangeMipmaps");
+  uint32_t nm = 0;
+  NAPI_OK(napi_get_array_length(env, mips, &nm));
+  const uint16_t* mp[3] = {0, 0, 0};
+  uint32_t ms[3][3];
+  if (nm > 3) nm = 3;
+  for (uint32_t k = 0; k < nm; ++k) {
+    napi_value e;
+    void* d;
+    NAPI_OK(napi_get_element(env, mips, k, &e));
+    if (!typed(env, prop(env, e, "mipmap"), napi_uint16_array, &d, &n)) return NULL;
+    mp[k] = (const uint16_t*)d;
+    if (!u32x3(env, prop(env, e, "stride"), ms[k])) return NULL;
+  }
+  if (vx_upload_volume(c, (const uint32_t*)ind, is, (const uint16_t*)rng, rs, (const uint8_t*)atl, as, (int)nm, mp,
+                       (const uint32_t(*)[3])ms, ext) != VX_OK)
+    return throw_msg(env, vx_last_error(c));
+  return NULL;
+}
+
+static napi_value n_upload_transfer(napi_env env, napi_callback_info info) {
+  napi_value a[3];
+  if (!get_args(env, info, 3, a)) return NULL;
+  VxContext* c = get_ctx(env, a[0]);
+  if (!c) return NULL;
+  void* d;
+  size_t n;
+  uint32_t len;
+  if (!typed(env, a[1], napi_float32_array, &d, &n)) return NULL;
+  NAPI_OK(napi_get_value_uint32(env, a[2], &len));
+  if (n < (size_t)len * 4) return throw_msg(env, "uploadTransfer: data shorter than length*4");
+  if (vx_upload_transfer(c, (const float*)d, len) != VX_OK) return throw_msg(env, vx_last_error(c));
+  return NULL;
+}
+
+/* setParams(ctx, ArrayBuffer holding one VxParams) */
+static napi_value n_set_params(napi_env env, napi_callback_info info) {
+  napi_value a[2];
+  if (!get_args(env, info, 2, a)) return NULL;
+  VxContext* c = get_ctx(env, a[0]);
+  if (!c) return NULL;
+  void* d;
+  size_t n;
+  NAPI_OK(napi_get_arraybuffer_info(env, a[1], &d, &n));
+  if (n != sizeof(VxParams)) return throw_msg(env, "setParams: buffer is not sizeof(VxParams)");
+  if (vx_set_params(c, (const VxParams*)d) != VX_OK) return throw_msg(env, vx_last_error(c));
+  return NULL;
+}
+
+static napi_value n_sizeof_params(napi_env env, napi_callback_info info) {
+  (void)info;
+  napi_value v;
+  NAPI_OK(napi_create_uint32(env, (uint32_t)sizeof(VxParams), &v));
+  return v;
+}
+
+static napi_value n_resize(napi_env env, napi_callback_info info) {
+  napi_value a[3];
+  if (!get_args(env, info, 3, a)) return NULL;
+  VxContext* c = get_ctx(env, a[0]);
+  if (!c) return NULL;
+  uint32_t w, h;
+  NAPI_OK(napi_get_value_uint32(env, a[1], &w));
+  NAPI_OK(napi_get_value_uint32(env, a[2], &h));
+  if (vx_resize(c, w, h) != VX_OK) return throw_msg(env, vx_last_error(c));
+  return NULL;
+}
+
+static napi_value n_set_layout(napi_env env, napi_callback_info info) {
+  napi_value a[2];
+  if (!get_args(env, info, 2, a)) return NULL;
+  VxContext* c = get_ctx(env, a[0]);
+  if (!c) return NULL;
+  int32_t l;
+  NAPI_OK(napi_get_value_int32(env, a[1], &l));
+  if (vx_set_layout(c, l) != VX_OK) return throw_msg(env, vx_last_error(c));
+  return NULL;
+}
+
+static napi_value n_render_frame(napi_env env, napi_callback_info info) {
+  napi_value a[3];
+  if (!get_args(env, info, 3, a)) return NULL;
+  VxContext* c = get_ctx(env, a[0]);
+  if (!c) return NULL;
+  uint32_t f;
+  double w;
+  NAPI_OK(napi_get_value_uint32(env, a[1], &f));
+  NAPI_OK(napi_get_value_double(env, a[2], &w));
+  if (vx_render_frame(c, f, (float)w) != VX_OK) return throw_msg(env, vx_last_error(c));
+  return NULL;
+}
+
+static napi_value n_finish(napi_env env, napi_callback_info info) {
+  napi_value a[1];
+  if (!get_args(env, info, 1, a)) return NULL;
+  VxContext* c = get_ctx(env, a[0]);
+  if (!c) return NULL;
+  if (vx_finish(c) != VX_OK) return throw_msg(env, vx_last_error(c));
+  return NULL;
+}
+
+static napi_value n_read_accum(napi_env env, napi_callback_info info) {
+  napi_value a[2];
+  if (!get_args(env, info, 2, a)) return NULL;
+  VxContext* c = get_ctx(env, a[0]);
+  if (!c) return NULL;
+  void* d;
+  size_t n;
+  if (!typed(env, a[1], napi_float32_array, &d, &n)) return NULL;
+  if (vx_read_accum(c, (float*)d) != VX_OK) return throw_msg(env, vx_last_error(c));
+  return NULL;
+}
+
+static napi_value n_read_display(napi_env env, napi_callback_info info) {
+  napi_value a[4];
+  if (!get_args(env, info, 4, a)) return NULL;
+  VxContext* c = get_ctx(env, a[0]);
+  if (!c) return NULL;
+  void* d;
+  size_t n;
+  double ex, ga;
+  if (!typed(env, a[1], napi_uint8_array, &d, &n)) return NULL;
+  NAPI_OK(napi_get_value_double(env, a[2], &ex));
+  NAPI_OK(napi_get_value_double(env, a[3], &ga));
+  if (vx_read_display(c, (uint8_t*)d, (float)ex, (float)ga) != VX_OK) return throw_msg(env, vx_last_error(c));
+  return NULL;
+}
+
+static napi_value n_get_counters(napi_env env, napi_callback_info info) {
+  napi_value a[1];
+  if (!get_args(env, info, 1, a)) return NULL;
+  VxContext* c = get_ctx(env, a[0]);
+  if (!c) return NULL;
+  VxCounters k;
+  if (vx_get_counters(c, &k) != VX_OK) return throw_msg(env, vx_last_error(c));
+  napi_value o, v;
+  NAPI_OK(napi_create_object(env, &o));
+#define PUT(name, val)                                      \
+  NAPI_OK(napi_create_double(env, (double)(val), &v));      \
+  NAPI_OK(napi_set_named_property(env, o, name, v));
+  PUT("samples", k.samples) PUT("rays", k.rays) PUT("pixels", k.pixels) PUT("skipSteps", k.skip_steps)
+  PUT("gradSamples", k.grad_samples) PUT("laneSlots", k.lane_slots) PUT("launches", k.launches)
+  PUT("kernelMs", k.kernel_ms) PUT("lastKernelMs", k.last_kernel_ms)
+#undef PUT
+  return o;
+}
+
+static napi_value n_reset_counters(napi_env env, napi_callback_info info) {
+  napi_value a[1];
+  if (!get_args(env, info, 1, a)) return NULL;
+  VxContext* c = get_ctx(env, a[0]);
+  if (c && vx_reset_counters(c) != VX_OK) return throw_msg(env, vx_last_error(c));
+  return NULL;
+}
+
+static napi_value n_version(napi_env env, napi_callback_info info) {
+  (void)info;
+  napi_value v;
+  NAPI_OK(napi_create_string_utf8(env, vx_version(), NAPI_AUTO_LENGTH, &v));
+  return v;
+}
+
+/* ---- preprocessor: buildBrickGrid(Uint16Array voxels, [x,y,z], [sx,sy,sz], maxValue, threads)
+ *      -> WasmWorkerMessageDicomReturn-shaped object (worker.ts:19-58 copies every buffer out
+ *      and frees the grid; so does this) */
+static napi_value make_typed(napi_env env, napi_typedarray_type t, const void* src, size_t count, size_t esz) {
+  napi_value ab, ta;
+  void* dst = NULL;
+  if (napi_create_arraybuffer(env, count * esz, &dst, &ab) != napi_ok) return NULL;
+  if (count) memcpy(dst, src, count * esz);
+  if (napi_create_typedarray(env, t, count, ab, 0, &ta) != napi_ok) return NULL;
+  return ta;
+}
+static napi_value make_u32x3(napi_env env, const uint32_t s[3]) {
+  napi_value arr, e;
+  napi_create_array_with_length(env, 3, &arr);
+  for (uint32_t i = 0; i < 3; ++i) {
+    napi_create_uint32(env, s[i], &e);
+    napi_set_element(env, arr, i, e);
+  }
+  return arr;
+}
+
+static napi_value n_build_brick_grid(napi_env env, napi_callback_info info) {
+  napi_value a[5];
+  if (!get_args(env, info, 5, a)) return NULL;
+  void* vox;
+  size_t n;
+  uint32_t dims[3], maxv;
+  int32_t threads;
+  float sp[3];
+  if (!typed(env, a[0], napi_uint16_array, &vox, &n) || !u32x3(env, a[1], dims)) return NULL;
+  for (uint32_t i = 0; i < 3; ++i) {
+    napi_value e;
+    double d;
+    NAPI_OK(napi_get_element(env, a[2], i, &e));
+    NAPI_OK(napi_get_value_double(env, e, &d));
+    sp[i] = (float)d;
+  }
+  NAPI_OK(napi_get_value_uint32(env, a[3], &maxv));
+  NAPI_OK(napi_get_value_int32(env, a[4], &threads));
+  if (n != (size_t)dims[0] * dims[1] * dims[2]) return throw_msg(env, "buildBrickGrid: voxel count != x*y*z");
+  VxBrickGrid* g = NULL;
+  if (vxb_build_from_u16((const uint16_t*)vox, dims, sp, (uint16_t)maxv, threads, &g) != VXB_OK)
+    return throw_msg(env, vxb_last_error());
+  uint32_t is[3], rs[3], as[3], ext[3];
+  vxb_indirection_size(g, is);
+  vxb_range_size(g, rs);
+  vxb_atlas_size(g, as);
+  vxb_index_extent(g, ext);
+  size_t nb = (size_t)is[0] * is[1] * is[2];
+  napi_value o, v;
+  napi_create_object(env, &o);
+  napi_create_string_utf8(env, "return_dicom", NAPI_AUTO_LENGTH, &v);
+  napi_set_named_property(env, o, "type", v);
+  napi_set_named_property(env, o, "indirectionSize", make_u32x3(env, is));
+  napi_set_named_property(env, o, "rangeSize", make_u32x3(env, rs));
+  napi_set_named_property(env, o, "atlasSize", make_u32x3(env, as));
+  napi_set_named_property(env, o, "indexExtent", make_u32x3(env, ext));
+  napi_set_named_property(env, o, "indirection", make_typed(env, napi_uint32_array, vxb_indirection_data(g), nb, 4));
+  napi_set_named_property(env, o, "range", make_typed(env, napi_uint16_array, vxb_range_data(g), nb * 2, 2));
+  napi_set_named_property(env, o, "atlas",
+                          make_typed(env, napi_uint8_array, vxb_atlas_data(g), (size_t)as[0] * as[1] * as[2], 1));
+  float t[16];
+  vxb_transform(g, t);
+  napi_set_named_property(env, o, "transform", make_typed(env, napi_float32_array, t, 16, 4));
+  uint32_t hl = vxb_histogram_len(g);
+  napi_set_named_property(env, o, "histogram", make_typed(env, napi_uint32_array, vxb_histogram(g), hl, 4));
+  napi_set_named_property(env, o, "histogramGradient",
+                          make_typed(env, napi_int32_array, vxb_histogram_gradient(g), hl, 4));
+  napi_value pair, e;
+  napi_create_array_with_length(env, 2, &pair);
+  napi_create_uint32(env, vxb_histogram_gradient_min(g), &e);
+  napi_set_element(env, pair, 0, e);
+  napi_create_uint32(env, vxb_histogram_gradient_max(g), &e);
+  napi_set_element(env, pair, 1, e);
+  napi_set_named_property(env, o, "histogramGradientRange", pair);
+  napi_create_array_with_length(env, 2, &pair);
+  napi_create_double(env, vxb_minorant(g), &e);
+  napi_set_element(env, pair, 0, e);
+  napi_create_double(env, vxb_majorant(g), &e);
+  napi_set_element(env, pair, 1, e);
+  napi_set_named_property(env, o, "minMaj", pair);
+  napi_value mips;
+  uint32_t nm = vxb_range_mipmaps(g);
+  napi_create_array_with_length(env, nm, &mips);
+  for (uint32_t k = 0; k < nm; ++k) {
+    uint32_t st[3];
+    vxb_range_mipmap_stride(g, k, st);
+    napi_value mo;
+    napi_create_object(env, &mo);
+    napi_set_named_property(env, mo, "mipmap",
+                            make_typed(env, napi_uint16_array, vxb_range_mipmap(g, k), (size_t)st[0] * st[1] * st[2] * 2, 2));
+    napi_set_named_property(env, mo, "stride", make_u32x3(env, st));
+    napi_set_element(env, mips, k, mo);
+  }
+  napi_set_named_property(env, o, "rangeMipmaps", mips);
+  napi_create_uint32(env, vxb_brick_counter(g), &e);
+  napi_set_named_property(env, o, "brickCounter", e);
+  vxb_free(g); /* worker.ts:54 */
+  return o;
+}
+
+static napi_value init(napi_env env, napi_value exports) {
+  static const struct { const char* name; napi_callback fn; } fns[] = {
+      {"create", n_create}, {"destroy", n_destroy}, {"uploadVolume", n_upload_volume},
+      {"uploadTransfer", n_upload_transfer}, {"setParams", n_set_params}, {"sizeofParams", n_sizeof_params},
+      {"resize", n_resize}, {"setLayout", n_set_layout}, {"renderFrame", n_render_frame}, {"finish", n_finish},
+      {"readAccum", n_read_accum}, {"readDisplay", n_read_display}, {"getCounters", n_get_counters},
+      {"resetCounters", n_reset_counters}, {"version", n_version}, {"buildBrickGrid", n_build_brick_grid}};
+  for (size_t i = 0; i < sizeof fns / sizeof fns[0]; ++i) {
+    napi_value f;
+    if (napi_create_function(env, fns[i].name, NAPI_AUTO_LENGTH, fns[i].fn, NULL, &f) != napi_ok ||
+        napi_set_named_property(env, exports, fns[i].name, f) != napi_ok) {
+      napi_throw_error(env, NULL, "volxel_napi: export failed");
+      return NULL;
+    }
+  }
+  return exports;
+}
+
+NAPI_MODULE(volxel_napi, init)
