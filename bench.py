@@ -94,6 +94,12 @@ def main():
     ap.add_argument("--force-gather", action="store_true", help="run the gather path with one rank too (testing)")
     a = ap.parse_args()
 
+    # the contract is ONE JSON line on stdout: keep a private handle to the real stdout and send
+    # everything else written to fd 1 (RCCL prints a version banner there) to stderr
+    sys.stdout.flush()
+    real_stdout = os.fdopen(os.dup(1), "w")
+    os.dup2(2, 1)
+
     import torch
     import torch.distributed as dist
 
@@ -226,7 +232,8 @@ def main():
             out["cpu_baseline"] = cpu_baseline(r, msg)
         else:
             out["cpu_baseline"] = None
-        print(json.dumps(out), flush=True)
+        real_stdout.write(json.dumps(out) + "\n")
+        real_stdout.flush()
     if use_dist:
         dist.barrier(device_ids=[local])
         dist.destroy_process_group()
