@@ -107,6 +107,9 @@ typedef struct VxParams {
                             (fragment.frag:146, raymarch.glsl:330); 0: pixel centre,
                             start offset 0.5 step                                        */
   int32_t dvr_max_steps;
+  int32_t dvr_skip_empty; /* 1: exact empty-space skipping -- samples whose macro cell (16..64
+                             voxels) can only see TF-transparent bricks are
+                             not evaluated (their alpha is exactly 0) and not counted          */
   float dvr_gain[3];     /* albedo * mis * f_p * Le / pdf  (fragment.frag:94-97), host-computed */
   /* Phong terms of VX_MODE_DVR_PHONG */
   float phong_ka, phong_kd, phong_ks, phong_shininess;
@@ -211,6 +214,10 @@ const char* vx_version(void);
 
 /* test hook (no reference counterpart): the device's R8-unorm decode table, 256 floats */
 int vx_debug_unorm_table(VxContext* ctx, float* out256);
+/* test hook: the host-built empty-space bitmask (pure CPU; bits_out may be NULL to query level/dims) */
+int vx_debug_build_skip_mask(const uint32_t* range_packed, const uint32_t brick_count[3], const float* tf_rgba,
+                             uint32_t tf_len, const VxParams* params, uint32_t* bits_out, uint32_t* level_out,
+                             uint32_t dims_out[3]);
 
 #ifdef __cplusplus
 }

@@ -114,6 +114,9 @@ def lib():
     L.vxo_render.restype = C.c_int
     L.vxo_primary_ray.argtypes = [P(VxParams), u32, i32, i32, P(f32), P(f32)]
     L.vxo_blit.argtypes = [vp, u32, f32, f32, vp, vp]
+    L.vxo_skip_level.argtypes = [P(VxoVolume)]; L.vxo_skip_level.restype = C.c_int
+    L.vxo_skip_dims.argtypes = [P(VxoVolume), C.c_int, P(u32)]
+    L.vxo_build_skip_mask.argtypes = [P(VxParams), P(VxoVolume), vp, u32, C.c_int, vp]
     _lib = L
     return L
 
@@ -265,3 +268,18 @@ def blit(accum, exposure=5.5, gamma=2.2):
     outf = np.zeros((n, 4), dtype=np.float32)
     L.vxo_blit(a.ctypes.data, n, exposure, gamma, out8.ctypes.data, outf.ctypes.data)
     return out8.reshape(a.shape), outf.reshape(a.shape)
+
+
+def skip_mask(params, grid, tf, tf_len):
+    """(level, dims, bits) of the exact empty-space mask (vxo_build_skip_mask)"""
+    L = lib()
+    p = copy_params(params)
+    vol = grid if isinstance(grid, VxoVolume) else make_volume(grid)
+    tf = np.ascontiguousarray(tf, dtype=np.float32)
+    level = L.vxo_skip_level(C.byref(vol))
+    dims = (C.c_uint32 * 3)()
+    L.vxo_skip_dims(C.byref(vol), level, dims)
+    n = dims[0] * dims[1] * dims[2]
+    bits = np.zeros((n + 31) // 32, dtype=np.uint32)
+    L.vxo_build_skip_mask(C.byref(p), C.byref(vol), tf.ctypes.data, tf_len, level, bits.ctypes.data)
+    return level, tuple(dims), bits

@@ -504,6 +504,9 @@ typedef struct {
   uint32_t tf_len;
   uint32_t frame;
   VxoCounters c;
+  const uint32_t* skip_bits; /* NULL: skipping off */
+  int skip_level;
+  uint32_t skip_dims[3];
 } Ctx;
 
 typedef struct { v3 o, d; } Ray;
@@ -890,6 +893,82 @@ static void trace_path(Ctx* k, Ray ray, uint32_t s[4], float out[4]) {
   out[3] = gl_clamp((float)n_paths, 0.0f, 1.0f);
 }
 
+
+/* ---- [build] exact empty-space skipping ------------------------------------------------- */
+int vxo_skip_level(const VxoVolume* v) {
+  for (int g = 1; g <= 3; ++g) {
+    uint64_t n = 1;
+    for (int a = 0; a < 3; ++a) n *= (uint64_t)(v->index_extent[a] >> (3 + g)) + 1u;
+    if (n <= 65536u) return g;
+  }
+  return 3;
+}
+void vxo_skip_dims(const VxoVolume* v, int level, uint32_t dims[3]) {
+  for (int a = 0; a < 3; ++a) dims[a] = (v->index_extent[a] >> (3 + level)) + 1u;
+}
+/* TF bin i can produce no opacity: alpha 0, or wholly outside the sample range (one-bin margin) */
+static int bin_dead(const VxParams* p, const float* tf, uint32_t L, int32_t i) {
+  if (tf[4 * (size_t)i + 3] == 0.0f) return 1;
+  float lf = (float)L;
+  if ((float)(i + 2) / lf < p->sample_range[0]) return 1;
+  if ((float)(i - 1) / lf > p->sample_range[1]) return 1;
+  return 0;
+}
+/* every density in [lo, hi] maps to dead bins (bins I(lo)-1 .. I(hi)+1) */
+static int range_transparent(const VxParams* p, const float* tf, uint32_t L, float lo, float hi) {
+  float lf = (float)L;
+  int32_t a = f2i(floorf(((lo * p->volume_density_scale) * p->volume_inv_maj) * lf)) - 1;
+  int32_t b = f2i(floorf(((hi * p->volume_density_scale) * p->volume_inv_maj) * lf)) + 1;
+  if (a < 0) a = 0;
+  if (b > (int32_t)L - 1) b = (int32_t)L - 1;
+  for (int32_t i = a; i <= b; ++i)
+    if (!bin_dead(p, tf, L, i)) return 0;
+  return 1;
+}
+void vxo_build_skip_mask(const VxParams* p, const VxoVolume* v, const float* tf, uint32_t L, int level,
+                         uint32_t* bits) {
+  uint32_t md[3];
+  vxo_skip_dims(v, level, md);
+  size_t n = (size_t)md[0] * md[1] * md[2];
+  memset(bits, 0, ((n + 31) / 32) * 4);
+  size_t nb = (size_t)v->range_size[0] * v->range_size[1] * v->range_size[2];
+  uint8_t* bt = (uint8_t*)malloc(nb ? nb : 1); /* per-brick transparency */
+  for (size_t i = 0; i < nb; ++i)
+    bt[i] = (uint8_t)range_transparent(p, tf, L, vxo_f16_to_f32(v->range[2 * i + 1]), vxo_f16_to_f32(v->range[2 * i]));
+  int zero_ok = range_transparent(p, tf, L, 0.0f, 0.0f);
+  int32_t w = 1 << level; /* bricks per macro cell and axis */
+  for (uint32_t mz = 0; mz < md[2]; ++mz)
+    for (uint32_t my = 0; my < md[1]; ++my)
+      for (uint32_t mx = 0; mx < md[0]; ++mx) {
+        int32_t lo[3] = {(int32_t)mx * w - 1, (int32_t)my * w - 1, (int32_t)mz * w - 1};
+        int empty = 1;
+        for (int32_t bz = lo[2]; bz <= lo[2] + w && empty; ++bz)
+          for (int32_t by = lo[1]; by <= lo[1] + w && empty; ++by)
+            for (int32_t bx = lo[0]; bx <= lo[0] + w && empty; ++bx) {
+              if (bx < 0 || by < 0 || bz < 0 || (uint32_t)bx >= v->range_size[0] ||
+                  (uint32_t)by >= v->range_size[1] || (uint32_t)bz >= v->range_size[2])
+                empty = zero_ok;
+              else
+                empty = bt[buf_index(v->range_size, (uint32_t)bx, (uint32_t)by, (uint32_t)bz)];
+            }
+        if (empty) {
+          size_t i = ((size_t)mz * md[1] + my) * md[0] + mx;
+          bits[i >> 5] |= 1u << (i & 31);
+        }
+      }
+  free(bt);
+}
+static inline int sample_is_skipped(const Ctx* k, v3 ip) {
+  if (!k->skip_bits) return 0;
+  int sh = 3 + k->skip_level;
+  int32_t cx = f2i(floorf(ip.x - 0.5f)) + 1, cy = f2i(floorf(ip.y - 0.5f)) + 1, cz = f2i(floorf(ip.z - 0.5f)) + 1;
+  if (cx < 0 || cy < 0 || cz < 0) return 0;
+  uint32_t mx = (uint32_t)cx >> sh, my = (uint32_t)cy >> sh, mz = (uint32_t)cz >> sh;
+  if (mx >= k->skip_dims[0] || my >= k->skip_dims[1] || mz >= k->skip_dims[2]) return 0;
+  size_t i = ((size_t)mz * k->skip_dims[1] + my) * k->skip_dims[0] + mx;
+  return (k->skip_bits[i >> 5] >> (i & 31)) & 1u;
+}
+
 /* ---- [build] deterministic DVR = E[RAYMARCH, bounces 1, no shadow term] ------------- */
 /* SURVEY.md section 8 row A12 / Appendix A.5.  Loop body restates raymarch.glsl:38-52
  * with lookup_density_trilinear (common.glsl:61-69) in place of the stochastic tap and the
@@ -914,6 +993,7 @@ static void dvr_pixel(Ctx* k, Ray ray, float start_offset, int phong, float out[
       float t = fmaf(kf, dt, t0);
       if (!(t < far)) break;
       v3 ip = madd3(ipos, t, idir);
+      if (sample_is_skipped(k, ip)) { k->c.skip_steps++; continue; } /* alpha would be exactly 0 */
       float d = trilinear(k, ip);
       float rgba[4];
       lookup_transfer(k, d * p->volume_inv_maj, rgba);
@@ -1035,6 +1115,16 @@ int vxo_render(const VxParams* p, uint32_t frame_index, float sample_weight, con
   Ctx k;
   memset(&k, 0, sizeof k);
   k.p = p; k.v = v; k.tf = tf; k.tf_len = tf_len; k.frame = frame_index;
+  uint32_t* mask = NULL;
+  if (p->dvr_skip_empty && (p->render_mode == VX_MODE_DVR || p->render_mode == VX_MODE_DVR_PHONG) &&
+      !p->debug_hits) {
+    k.skip_level = vxo_skip_level(v);
+    vxo_skip_dims(v, k.skip_level, k.skip_dims);
+    size_t n = (size_t)k.skip_dims[0] * k.skip_dims[1] * k.skip_dims[2];
+    mask = (uint32_t*)malloc(((n + 31) / 32) * 4);
+    vxo_build_skip_mask(p, v, tf, tf_len, k.skip_level, mask);
+    k.skip_bits = mask;
+  }
   int32_t W = p->res[0];
   float w = sample_weight;
   for (int32_t py = y0; py < y1; ++py)
@@ -1051,6 +1141,7 @@ int vxo_render(const VxParams* p, uint32_t frame_index, float sample_weight, con
       k.c.pixels++;
     }
   if (counters) *counters = k.c;
+  free(mask);
   return 0;
 }
 

@@ -87,6 +87,17 @@ int vxo_render(const VxParams* p, uint32_t frame_index, float sample_weight, con
                const float* tf, uint32_t tf_len, const float* prev, float* out, int32_t x0,
                int32_t x1, int32_t y0, int32_t y1, VxoCounters* counters);
 
+/* [build] exact empty-space skipping of VX_MODE_DVR.  Macro-cell lattice at
+ * level g: cell c = floor(p-0.5) belongs to macro cell (c+1) >> (3+g); dims[a] =
+ * (index_extent[a] >> (3+g)) + 1.  A macro cell is EMPTY iff every brick that can hold a tap of
+ * one of its cells (and the value 0 outside the grid) is transparent under the current TF /
+ * sample range.  vxo_skip_level picks the smallest g in 1..3 whose lattice has <= 65536 cells.
+ * bits: one bit per macro cell, x fastest, word = index >> 5. */
+int vxo_skip_level(const VxoVolume* v);
+void vxo_skip_dims(const VxoVolume* v, int level, uint32_t dims[3]);
+void vxo_build_skip_mask(const VxParams* p, const VxoVolume* v, const float* tf, uint32_t tf_len,
+                         int level, uint32_t* bits);
+
 /* primary ray of a pixel (fragment.frag:57-65,140-146), for ray-gen tests */
 void vxo_primary_ray(const VxParams* p, uint32_t frame_index, int32_t px, int32_t py,
                      float origin[3], float dir[3]);

@@ -174,6 +174,31 @@ def test_progressive_accumulation_matches_oracle(oracle):
     assert np.abs(r2.read_accum() - prev).max() <= 4e-6
 
 
+@pytest.mark.parametrize("layout", [0, 1, 2])
+def test_empty_space_skipping_is_exact(oracle, layout):
+    """skipping on/off: identical pixels, sample counts equal to the oracle's in both settings"""
+    from tests.common import make_scene, benchmark_tf, BENCH_CAM
+    from volxel_amd import synth
+    inner, sp = synth.value_noise(64, seed=5, zero_quantile=0.6)
+    vox = np.zeros((128, 128, 128), dtype=np.uint16)
+    vox[20:84, 30:94, 40:104] = inner
+    g = oracle.BrickGrid(vox, sp)
+    tf, L = benchmark_tf()
+    s, cam, vol, ds, p = make_scene(g, 160, 96, "dvr", sample_range=(0.05645751953125, 1.0), **BENCH_CAM)
+    r = _renderer(g, tf, L, p, layout)
+    imgs, counts = [], []
+    for skip in (1, 0):
+        p.dvr_skip_empty = skip
+        want, oc = oracle.render(p, g, tf, L)
+        r.reset_counters()
+        img = _render_with_params(r, p)
+        c = r.counters()
+        assert np.abs(img - want).max() <= 2e-6
+        assert c.samples == oc.samples
+        imgs.append(img); counts.append(c.samples)
+    assert np.array_equal(imgs[0], imgs[1]) and counts[0] < counts[1]
+
+
 def test_display_pass_matches_blit(oracle):
     from tests.golden.make_golden import build_case
     grid, tf, L, p, frame = build_case(oracle, "noise32_dvr_clip")

@@ -226,3 +226,48 @@ int main(void){ int bad=0; const float r=1.0f/255.0f;
         open(os.path.join(d, "t.c"), "w").write(src)
         subprocess.check_call(["gcc", "-O0", "-ffp-contract=off", os.path.join(d, "t.c"), "-o", os.path.join(d, "t"), "-lm"])
         assert subprocess.check_output([os.path.join(d, "t")]).strip() == b"0"
+
+
+@pytest.mark.parametrize("case", ["noise_bench_tf", "sphere_default_tf", "ct_narrow_range"])
+def test_skip_mask_matches_oracle_and_is_exact(native_lib, oracle, case):
+    """the library's host-built empty-space mask equals the oracle's restatement of the rule, and
+    skipping never changes a pixel (the skipped samples have alpha == 0 exactly)"""
+    from tests.common import make_scene, benchmark_tf, BENCH_CAM
+    from volxel_amd import default_transfer_function
+    if case == "noise_bench_tf":
+        inner, sp = synth.value_noise(64, seed=5, zero_quantile=0.6)
+        vox = np.zeros((128, 128, 128), dtype=np.uint16)      # noise block inside empty space
+        vox[20:84, 30:94, 40:104] = inner
+        tf, L = benchmark_tf()
+        kw = dict(sample_range=(0.05645751953125, 1.0), **BENCH_CAM)
+    elif case == "sphere_default_tf":
+        vox, sp = synth.sphere(64)
+        tf, L = default_transfer_function()
+        kw = dict(sample_range=(0.1, 0.9))
+    else:
+        vox, sp = synth.ct_phantom(64)
+        tf, L = benchmark_tf()
+        kw = dict(sample_range=(0.3, 0.5), density_multiplier=0.99, **BENCH_CAM)
+    g = oracle.BrickGrid(vox, sp)
+    s, cam, vol, ds, p = make_scene(g, 64, 48, "dvr", **kw)
+    level, dims, bits = oracle.skip_mask(p, g, tf, L)
+    bc = (C.c_uint32 * 3)(*g.brick_count)
+    lvl, md = C.c_uint32(), (C.c_uint32 * 3)()
+    got = np.zeros_like(bits)
+    rp = np.ascontiguousarray(g.range_packed, dtype=np.uint32)
+    tfa = np.ascontiguousarray(tf, dtype=np.float32)
+    pp = _abi.VxParams()
+    C.memmove(C.byref(pp), C.byref(p), C.sizeof(pp))
+    rc = native_lib.vx_debug_build_skip_mask(rp.ctypes.data, bc, tfa.ctypes.data, L, C.byref(pp), got.ctypes.data,
+                                             C.byref(lvl), md)
+    assert rc == 0 and lvl.value == level and tuple(md) == dims
+    assert np.array_equal(got, bits)
+    n_empty = int(sum(bin(int(w)).count("1") for w in bits))
+    assert 0 < n_empty < dims[0] * dims[1] * dims[2]
+    # exactness: identical pixels with and without skipping, fewer evaluated samples
+    p.dvr_skip_empty = 1
+    a, ca = oracle.render(p, g, tf, L)
+    p.dvr_skip_empty = 0
+    b, cb = oracle.render(p, g, tf, L)
+    assert np.array_equal(a, b)
+    assert ca.samples < cb.samples and ca.samples + ca.skip_steps == cb.samples

@@ -41,6 +41,13 @@ struct VxContext {
   // transfer function
   float4* tf = nullptr;
   uint32_t tf_len = 0;
+  std::vector<float> tf_host;
+
+  // exact empty-space skipping (DVR): macro-cell bitmask, rebuilt when its inputs change
+  std::vector<uint32_t> range_host;   // packed (min16<<16)|max16 per brick
+  uint32_t* skip_dev = nullptr;
+  bool skip_dirty = true;
+  float skip_key[4] = {0, 0, 0, 0};   // density_scale, inv_maj, sample_range
 
   // params
   VxParams params{};
@@ -87,6 +94,7 @@ static void free_volume(VxContext* c) {
   c->bf_alloc = nullptr;
   c->dv = DevVolume{};
   c->has_volume = false;
+  c->skip_dirty = true;
 }
 
 static void drain_events(VxContext* c) {
@@ -128,6 +136,115 @@ static int alloc_framebuffers(VxContext* c) {
   VX_HIP(c, hipMalloc(&c->image, (size_t)c->W * c->H * sizeof(float4)));
   VX_HIP(c, hipMalloc(&c->display, (size_t)c->W * c->H * sizeof(uchar4)));
   VX_HIP(c, hipMemsetAsync(c->slab, 0, c->slab_quads * sizeof(float4), c->stream));
+  return VX_OK;
+}
+
+
+// ---- exact empty-space skipping: host-side construction of the macro-cell bitmask -------------
+// Rule (restated independently by the oracle): TF bin i is dead when its alpha
+// is 0 or it lies wholly outside the sample range (one-bin margin); a brick is transparent when
+// every bin from I(min)-1 to I(max)+1 is dead, I(x) = floor(x*density_scale*inv_maj*L); a macro
+// cell of w = 2^level bricks per axis is empty when the w+1 bricks per axis that can hold a tap of
+// its cells (bricks m*w-1 .. m*w+w-1; value 0 outside the grid) are all transparent.
+static float f16_bits_to_float(uint16_t h) {
+  _Float16 v;
+  memcpy(&v, &h, 2);
+  return (float)v;
+}
+static int skip_level_for(const uint32_t extent[3]) {
+  for (int g = 1; g <= 3; ++g) {
+    uint64_t n = 1;
+    for (int a = 0; a < 3; ++a) n *= (uint64_t)(extent[a] >> (3 + g)) + 1u;
+    if (n <= 65536u) return g;
+  }
+  return 3;
+}
+static void compute_skip_mask(const VxParams& p, const uint32_t* range_packed, const uint32_t bc[3],
+                              const uint32_t extent[3], const float* tf_rgba, uint32_t L,
+                              std::vector<uint32_t>& bits, int& level_out, uint32_t md[3]) {
+  const float lf = (float)L;
+  // prefix count of live bins -> O(1) "any live bin in [a, b]"
+  std::vector<uint32_t> live(L + 1, 0);
+  for (uint32_t i = 0; i < L; ++i) {
+    bool dead = tf_rgba[4 * (size_t)i + 3] == 0.0f || (float)((int)i + 2) / lf < p.sample_range[0] ||
+                (float)((int)i - 1) / lf > p.sample_range[1];
+    live[i + 1] = live[i] + (dead ? 0u : 1u);
+  }
+  auto transparent = [&](float lo, float hi) {
+    float fa = floorf(((lo * p.volume_density_scale) * p.volume_inv_maj) * lf);
+    float fb = floorf(((hi * p.volume_density_scale) * p.volume_inv_maj) * lf);
+    // v_cvt_i32_f32 semantics: NaN -> 0, saturating
+    auto f2i = [](float x) -> int64_t { return x != x ? 0 : (x >= 2147483648.0f ? 2147483647ll : (x <= -2147483648.0f ? -2147483648ll : (int64_t)x)); };
+    int64_t a = f2i(fa) - 1, b = f2i(fb) + 1;
+    if (a < 0) a = 0;
+    if (b > (int64_t)L - 1) b = (int64_t)L - 1;
+    if (b < a) return true;
+    return live[(size_t)b + 1] - live[(size_t)a] == 0u;
+  };
+  const size_t nb = (size_t)bc[0] * bc[1] * bc[2];
+  std::vector<uint8_t> opaque(nb);
+  for (size_t i = 0; i < nb; ++i) {
+    uint32_t pk = range_packed[i];
+    opaque[i] = transparent(f16_bits_to_float((uint16_t)(pk >> 16)), f16_bits_to_float((uint16_t)pk)) ? 0 : 1;
+  }
+  const uint8_t zero_opaque = transparent(0.0f, 0.0f) ? 0 : 1;
+  const int level = skip_level_for(extent);
+  level_out = level;
+  const int w = 1 << level;
+  for (int a = 0; a < 3; ++a) md[a] = (extent[a] >> (3 + level)) + 1u;
+  // separable OR over the window [m*w-1, m*w+w-1] per axis (out-of-grid bricks count as value 0)
+  std::vector<uint8_t> ax((size_t)md[0] * bc[1] * bc[2]), ay((size_t)md[0] * md[1] * bc[2]);
+  for (uint32_t z = 0; z < bc[2]; ++z)
+    for (uint32_t y = 0; y < bc[1]; ++y)
+      for (uint32_t m = 0; m < md[0]; ++m) {
+        uint8_t o = 0;
+        for (int b = (int)m * w - 1; b <= (int)m * w + w - 1; ++b)
+          o |= (b < 0 || (uint32_t)b >= bc[0]) ? zero_opaque : opaque[((size_t)z * bc[1] + y) * bc[0] + b];
+        ax[((size_t)z * bc[1] + y) * md[0] + m] = o;
+      }
+  for (uint32_t z = 0; z < bc[2]; ++z)
+    for (uint32_t m = 0; m < md[1]; ++m)
+      for (uint32_t x = 0; x < md[0]; ++x) {
+        uint8_t o = 0;
+        for (int b = (int)m * w - 1; b <= (int)m * w + w - 1; ++b)
+          o |= (b < 0 || (uint32_t)b >= bc[1]) ? zero_opaque : ax[((size_t)z * bc[1] + b) * md[0] + x];
+        ay[((size_t)z * md[1] + m) * md[0] + x] = o;
+      }
+  const size_t n = (size_t)md[0] * md[1] * md[2];
+  bits.assign((n + 31) / 32, 0u);
+  for (uint32_t m = 0; m < md[2]; ++m)
+    for (uint32_t y = 0; y < md[1]; ++y)
+      for (uint32_t x = 0; x < md[0]; ++x) {
+        uint8_t o = 0;
+        for (int b = (int)m * w - 1; b <= (int)m * w + w - 1; ++b)
+          o |= (b < 0 || (uint32_t)b >= bc[2]) ? zero_opaque : ay[((size_t)b * md[1] + y) * md[0] + x];
+        if (!o) {
+          size_t i = ((size_t)m * md[1] + y) * md[0] + x;
+          bits[i >> 5] |= 1u << (i & 31);
+        }
+      }
+}
+
+static int rebuild_skip_mask(VxContext* c) {
+  const VxParams& p = c->params;
+  std::vector<uint32_t> bits;
+  int level = 1;
+  uint32_t md[3];
+  compute_skip_mask(p, c->range_host.data(), c->dv.bc, c->dv.extent, c->tf_host.data(), c->tf_len, bits, level, md);
+  if (c->skip_dev) (void)hipFree(c->skip_dev);
+  c->skip_dev = nullptr;
+  VX_HIP(c, hipMalloc(&c->skip_dev, bits.size() * 4));
+  VX_HIP(c, hipMemcpyAsync(c->skip_dev, bits.data(), bits.size() * 4, hipMemcpyHostToDevice, c->stream));
+  VX_HIP(c, hipStreamSynchronize(c->stream));
+  c->dv.skip_bits = c->skip_dev;
+  c->dv.skip_level = (uint32_t)level;
+  c->dv.skip_words = (uint32_t)bits.size();
+  for (int a = 0; a < 3; ++a) c->dv.skip_dims[a] = md[a];
+  c->skip_dirty = false;
+  c->skip_key[0] = p.volume_density_scale;
+  c->skip_key[1] = p.volume_inv_maj;
+  c->skip_key[2] = p.sample_range[0];
+  c->skip_key[3] = p.sample_range[1];
   return VX_OK;
 }
 
@@ -218,6 +335,7 @@ void vx_destroy(VxContext* c) {
   }
   free_volume(c);
   if (c->tf) (void)hipFree(c->tf);
+  if (c->skip_dev) (void)hipFree(c->skip_dev);
   if (c->slab) (void)hipFree(c->slab);
   if (c->image) (void)hipFree(c->image);
   if (c->display) (void)hipFree(c->display);
@@ -317,6 +435,8 @@ int vx_upload_volume(VxContext* c, const uint32_t* indirection, const uint32_t i
   c->dv.indirection = (const uint32_t*)d;
   if ((rc = up(range, nb * 4, &d))) return rc;  // u16 stream [max,min] == LE u32 (min<<16)|max
   c->dv.range = (const uint32_t*)d;
+  c->range_host.assign((const uint32_t*)range, (const uint32_t*)range + nb);
+  c->skip_dirty = true;
   if ((rc = up(atlas, atlas_bytes, &d))) return rc;
   c->dv.atlas = (const uint8_t*)d;
   for (int k = 0; k < 3; ++k) {
@@ -363,6 +483,8 @@ int vx_upload_transfer(VxContext* c, const float* rgba, uint32_t length) {
   VX_HIP(c, hipMalloc(&c->tf, (size_t)length * sizeof(float4)));
   VX_HIP(c, hipMemcpy(c->tf, rgba, (size_t)length * sizeof(float4), hipMemcpyHostToDevice));
   c->tf_len = length;
+  c->tf_host.assign(rgba, rgba + (size_t)length * 4);
+  c->skip_dirty = true;
   return VX_OK;
 }
 
@@ -409,6 +531,18 @@ int vx_render_frame(VxContext* c, uint32_t frame_index, float sample_weight) {
   if (!c->slab) VX_FAIL(c, VX_ERR_INVALID, "vx_render_frame: vx_resize not called");
   if ((uint32_t)c->params.res[0] != c->W || (uint32_t)c->params.res[1] != c->H)
     VX_FAIL(c, VX_ERR_INVALID, "vx_render_frame: params.res differs from the framebuffer size");
+  {
+    const VxParams& p = c->params;
+    bool dvr = p.render_mode == VX_MODE_DVR || p.render_mode == VX_MODE_DVR_PHONG;
+    if (dvr && p.dvr_skip_empty && !p.debug_hits) {
+      if (c->skip_dirty || !c->dv.skip_bits || c->skip_key[0] != p.volume_density_scale ||
+          c->skip_key[1] != p.volume_inv_maj || c->skip_key[2] != p.sample_range[0] ||
+          c->skip_key[3] != p.sample_range[1]) {
+        int rc = rebuild_skip_mask(c);
+        if (rc) return rc;
+      }
+    }
+  }
   EventPair ev;
   if (c->free_events.empty()) {
     if (c->pending_events.size() >= 4096) drain_events(c);
@@ -557,6 +691,23 @@ int vx_device_info(VxContext* c, char* name, uint32_t cap, uint32_t* cus, uint64
   }
   if (cus) *cus = (uint32_t)c->prop.multiProcessorCount;
   if (hbm) *hbm = (uint64_t)c->prop.totalGlobalMem;
+  return VX_OK;
+}
+
+// test hook: the host-side skip mask for a brick grid / TF / uniforms (pure CPU, no context).
+// bits_out must hold ((prod(dims)+31)/32) words; call with bits_out == NULL to get level / dims.
+int vx_debug_build_skip_mask(const uint32_t* range_packed, const uint32_t brick_count[3], const float* tf_rgba,
+                             uint32_t tf_len, const VxParams* p, uint32_t* bits_out, uint32_t* level_out,
+                             uint32_t dims_out[3]) {
+  if (!range_packed || !brick_count || !tf_rgba || !tf_len || !p) return VX_ERR_INVALID;
+  uint32_t extent[3] = {brick_count[0] * 8u, brick_count[1] * 8u, brick_count[2] * 8u};
+  std::vector<uint32_t> bits;
+  int level = 1;
+  uint32_t md[3];
+  compute_skip_mask(*p, range_packed, brick_count, extent, tf_rgba, tf_len, bits, level, md);
+  if (level_out) *level_out = (uint32_t)level;
+  if (dims_out) { dims_out[0] = md[0]; dims_out[1] = md[1]; dims_out[2] = md[2]; }
+  if (bits_out) memcpy(bits_out, bits.data(), bits.size() * 4);
   return VX_OK;
 }
 

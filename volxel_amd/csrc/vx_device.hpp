@@ -34,7 +34,19 @@ struct DevVolume {
   uint32_t cq_bc[3];            // bc + 1
   // MI355X layout "brickf32": every 8^3 brick decoded to fp32, 2 KiB contiguous, brick-major
   const float* bf;              // [bc.z][bc.y][bc.x][8][8][8]
+  // exact empty-space skipping (DVR): one bit per macro cell of 8 << skip_level voxels
+  const uint32_t* skip_bits;    // nullptr: none
+  uint32_t skip_level;
+  uint32_t skip_dims[3];        // (extent >> (3 + level)) + 1
+  uint32_t skip_words;
 };
+
+// macro cell of trilinear cell c (given as c+1 >= 0): is it flagged empty?
+VXD bool skip_test(const uint32_t* bits, uint32_t sh, uint32_t d0, uint32_t d1, uint32_t cx, uint32_t cy,
+                   uint32_t cz) {
+  uint32_t mi = ((cz >> sh) * d1 + (cy >> sh)) * d0 + (cx >> sh);
+  return (bits[mi >> 5] >> (mi & 31u)) & 1u;
+}
 
 constexpr uint32_t CQ_SLICE_QUADS = 64;                  // 8x8 cells per z slice
 constexpr uint32_t CQ_BRICK_QUADS = 9 * CQ_SLICE_QUADS;  // 576 float4 = 9216 B

@@ -67,14 +67,22 @@ VXD void dvr_store(const VxParams& p, const DvrRay& r, float Cx, float Cy, float
 // U = march steps per loop iteration: the 2*U gathers of a batch are issued back to back before
 // any of them is consumed, so a wave keeps 2*U loads in flight instead of 2 (the march is
 // latency-bound on the longest rays: tools/tail_probe.py).
-template <int U>
+// SKIP = exact empty-space skipping: the macro-cell bitmask (<= 8 KiB) sits in LDS next to the TF;
+// a sample in an empty macro cell is neither gathered nor counted (its alpha is exactly 0), and a
+// lane whose last sample of a batch was empty jumps to one step before the exit of that macro
+// cell.  Every jumped-over sample lies inside the same empty macro cell, so the set of evaluated
+// samples is exactly "samples whose macro cell is not empty" -- what the oracle counts.
+template <int U, bool SKIP>
 __global__ __launch_bounds__(256) void render_dvr_cq(const VxParams p, const DevVolume v,
                                                       const float4* __restrict__ tf_global,
                                                       uint32_t tf_len, float4* __restrict__ slab,
                                                       uint32_t frame, float weight, const TileMap tm,
                                                       DevCounters* __restrict__ dc) {
   extern __shared__ float4 tf_lds[];
+  uint32_t* mask_lds = reinterpret_cast<uint32_t*>(tf_lds + tf_len);
   for (uint32_t i = threadIdx.x; i < tf_len; i += blockDim.x) tf_lds[i] = tf_global[i];
+  if (SKIP)
+    for (uint32_t i = threadIdx.x; i < v.skip_words; i += blockDim.x) mask_lds[i] = v.skip_bits[i];
   __syncthreads();
   uint32_t lt, sub;
   if (!block_to_tile(blockIdx.x, tm, lt, sub)) return;
@@ -96,26 +104,30 @@ __global__ __launch_bounds__(256) void render_dvr_cq(const VxParams p, const Dev
   const float4* __restrict__ cq = v.cq;
   const uint32_t cmaxx = v.extent[0] + 7u, cmaxy = v.extent[1] + 7u, cmaxz = v.extent[2] + 7u;
   const float ert = p.dvr_ert_tau;
-  const int max_steps = p.dvr_max_steps;
+  const float max_steps_f = (float)p.dvr_max_steps;
+  const uint32_t sh = 3u + v.skip_level, md0 = v.skip_dims[0], md1 = v.skip_dims[1];
+  const float inv_dt = SKIP ? 1.0f / r.dt : 0.0f;
 
-  float Cx = 0.f, Cy = 0.f, Cz = 0.f, T = 1.0f, tau = 0.0f, kf = 0.0f;
-  int k = 0;
-  uint32_t n_samples = 0, n_slots = 0;  // wave-uniform
+  float Cx = 0.f, Cy = 0.f, Cz = 0.f, T = 1.0f, tau = 0.0f, kf = 0.0f;  // kf: per-lane step index
+  uint32_t n_samples = 0, n_slots = 0, n_skipped = 0;                   // wave-uniform
 
   while (true) {
     {
       float t = fma_(kf, r.dt, r.t0);
-      alive = alive && (t < r.far) && (k < max_steps);
+      alive = alive && (t < r.far) && (kf < max_steps_f);
       if (__ballot(alive) == 0ull) break;
     }
     // ---- phase 1: addresses + gathers of U consecutive steps --------------------------------
     float4 q0[U], q1[U];
     float fx[U], fy[U], fz[U];
     bool ok[U];
+    bool last_empty = false;
+    float lqx = 0.f, lqy = 0.f, lqz = 0.f;
+    uint32_t lcx = 0, lcy = 0, lcz = 0;
 #pragma unroll
     for (int u = 0; u < U; ++u) {
       float t = fma_(kf + (float)u, r.dt, r.t0);
-      ok[u] = alive && (t < r.far) && (k + u < max_steps);
+      bool in = alive && (t < r.far) && (kf + (float)u < max_steps_f);
       // A5 on the cellquad layout: cell (floor(p-0.5)) + 1 -> apron brick / local cell
       float qx = fma_(t, r.idir.x, r.ipos.x) - 0.5f;
       float qy = fma_(t, r.idir.y, r.ipos.y) - 0.5f;
@@ -126,11 +138,24 @@ __global__ __launch_bounds__(256) void render_dvr_cq(const VxParams p, const Dev
       // inside the clipped AABB these are always in the lattice; the clamp only makes a stray or
       // already finished ray read defined memory instead of faulting
       cx = cx < cmaxx ? cx : cmaxx; cy = cy < cmaxy ? cy : cmaxy; cz = cz < cmaxz ? cz : cmaxz;
+      bool eval = in;
+      if (SKIP) {
+        uint32_t mi = ((cz >> sh) * md1 + (cy >> sh)) * md0 + (cx >> sh);
+        bool empty = (mask_lds[mi >> 5] >> (mi & 31u)) & 1u;
+        eval = in && !empty;
+        n_skipped += (uint32_t)__builtin_popcountll(__ballot(in && empty));
+        if (u == U - 1) {
+          last_empty = in && empty;
+          lqx = qx; lqy = qy; lqz = qz;
+          lcx = cx; lcy = cy; lcz = cz;
+        }
+      }
+      ok[u] = eval;
       uint32_t b = ((cz >> 3) * cby + (cy >> 3)) * cbx + (cx >> 3);
       uint32_t cell = ((cz & 7u) << 6) | ((cy & 7u) << 3) | (cx & 7u);
-      // unconditional loads (finished lanes read quad 0): no control flow between the 2*U
-      // gathers, so they are all in flight before the first s_waitcnt
-      size_t o = ok[u] ? ((size_t)b * CQ_BRICK_QUADS + cell) : (size_t)0;
+      // unconditional loads (finished / skipped lanes read quad 0): no control flow between the
+      // 2*U gathers, so they are all in flight before the first s_waitcnt
+      size_t o = eval ? ((size_t)b * CQ_BRICK_QUADS + cell) : (size_t)0;
       q0[u] = cq[o];
       q1[u] = cq[o + CQ_SLICE_QUADS];
     }
@@ -175,12 +200,24 @@ __global__ __launch_bounds__(256) void render_dvr_cq(const VxParams p, const Dev
       }
     }
     kf += (float)U;
-    k += U;
+    if (SKIP && last_empty) {
+      // distance (in t) from the batch's last sample to the faces of its macro cell, along the ray
+      const float Sf = (float)(1u << sh);
+      float bx = (float)((lcx >> sh) << sh) - 1.0f, by = (float)((lcy >> sh) << sh) - 1.0f,
+            bz = (float)((lcz >> sh) << sh) - 1.0f;  // q in [b, b + S) inside the macro cell
+      float dx = r.idir.x > 0.0f ? (bx + Sf - lqx) / r.idir.x : (r.idir.x < 0.0f ? (bx - lqx) / r.idir.x : 3.0e38f);
+      float dy = r.idir.y > 0.0f ? (by + Sf - lqy) / r.idir.y : (r.idir.y < 0.0f ? (by - lqy) / r.idir.y : 3.0e38f);
+      float dz = r.idir.z > 0.0f ? (bz + Sf - lqz) / r.idir.z : (r.idir.z < 0.0f ? (bz - lqz) / r.idir.z : 3.0e38f);
+      float dmin = fminf(dx, fminf(dy, dz));
+      float n = floorf(dmin * inv_dt) - 2.0f;  // stay >= one whole step short of the exit face
+      n = fminf(n, 1048576.0f);
+      if (n >= 1.0f) kf += n;
+    }
   }
 
   if (in_image) dvr_store(p, r, Cx, Cy, Cz, T, weight, slab, si);
   const uint32_t n_px = (uint32_t)__builtin_popcountll(__ballot(in_image));
-  add_counts(dc, n_samples, n_rays, n_px, 0u, 0u, n_slots);
+  add_counts(dc, n_samples, n_rays, n_px, n_skipped, 0u, n_slots);
 }
 
 inline void launch_dvr_cq(const VxParams& p, const DevVolume& v, const float4* tf, uint32_t tf_len,
@@ -189,13 +226,24 @@ inline void launch_dvr_cq(const VxParams& p, const DevVolume& v, const float4* t
   uint32_t groups = (tm.tiles_per_shard + 7u) / 8u;
   static const int unroll = [] { const char* e = getenv("VX_DVR_UNROLL"); return e ? atoi(e) : 4; }();
   dim3 grid(groups * 128u), block(256);
-  size_t lds = (size_t)tf_len * sizeof(float4);
-  switch (unroll) {
-    case 1: hipLaunchKernelGGL(render_dvr_cq<1>, grid, block, lds, stream, p, v, tf, tf_len, slab, frame, weight, tm, dc); break;
-    case 2: hipLaunchKernelGGL(render_dvr_cq<2>, grid, block, lds, stream, p, v, tf, tf_len, slab, frame, weight, tm, dc); break;
-    case 8: hipLaunchKernelGGL(render_dvr_cq<8>, grid, block, lds, stream, p, v, tf, tf_len, slab, frame, weight, tm, dc); break;
-    default: hipLaunchKernelGGL(render_dvr_cq<4>, grid, block, lds, stream, p, v, tf, tf_len, slab, frame, weight, tm, dc); break;
+  const bool skip = p.dvr_skip_empty && v.skip_bits;
+  size_t lds = (size_t)tf_len * sizeof(float4) + (skip ? (size_t)v.skip_words * 4u : 0u);
+#define VX_LAUNCH(UU, SS) \
+  hipLaunchKernelGGL((render_dvr_cq<UU, SS>), grid, block, lds, stream, p, v, tf, tf_len, slab, frame, weight, tm, dc)
+  if (skip) {
+    switch (unroll) {
+      case 1: VX_LAUNCH(1, true); break;
+      case 2: VX_LAUNCH(2, true); break;
+      default: VX_LAUNCH(4, true); break;
+    }
+  } else {
+    switch (unroll) {
+      case 1: VX_LAUNCH(1, false); break;
+      case 2: VX_LAUNCH(2, false); break;
+      default: VX_LAUNCH(4, false); break;
+    }
   }
+#undef VX_LAUNCH
 }
 
 }  // namespace vx

@@ -77,6 +77,7 @@ __global__ __launch_bounds__(256) void render_dvr_tile(const VxParams p, const D
   const int last = (int)tf_len - 1;
   const float ert = p.dvr_ert_tau;
   const int max_steps = p.dvr_max_steps;
+  const bool skip = p.dvr_skip_empty && v.skip_bits;
 
   float Cx = 0.f, Cy = 0.f, Cz = 0.f, T = 1.0f, tau = 0.0f, kf = 0.0f;
   int k = 0;
@@ -196,15 +197,25 @@ __global__ __launch_bounds__(256) void render_dvr_tile(const VxParams p, const D
       float t = fma_(kf, r.dt, r.t0);
       alive = alive && (t < r.far) && (k < max_steps);
       unsigned long long m = __ballot(alive);
-      n_samples += (uint32_t)__builtin_popcountll(m);
       n_slots += (m != 0ull) ? 64u : 0u;
+      bool evaluated = false;
       if (alive) {
         float qx = fma_(t, r.idir.x, r.ipos.x) - 0.5f;
         float qy = fma_(t, r.idir.y, r.ipos.y) - 0.5f;
         float qz = fma_(t, r.idir.z, r.ipos.z) - 0.5f;
         float flx = floorf(qx), fly = floorf(qy), flz = floorf(qz);
-        taps((int)flx, (int)fly, (int)flz, qx - flx, qy - fly, qz - flz);
+        bool empty = false;
+        if (skip) {
+          uint32_t cx = (uint32_t)((int)flx + 1), cy = (uint32_t)((int)fly + 1), cz = (uint32_t)((int)flz + 1);
+          cx = cx < v.extent[0] + 7u ? cx : v.extent[0] + 7u;
+          cy = cy < v.extent[1] + 7u ? cy : v.extent[1] + 7u;
+          cz = cz < v.extent[2] + 7u ? cz : v.extent[2] + 7u;
+          empty = skip_test(v.skip_bits, 3u + v.skip_level, v.skip_dims[0], v.skip_dims[1], cx, cy, cz);
+        }
+        if (!empty) taps((int)flx, (int)fly, (int)flz, qx - flx, qy - fly, qz - flz);
+        evaluated = !empty;
       }
+      n_samples += (uint32_t)__builtin_popcountll(__ballot(evaluated));
       kf += 1.0f;
       ++k;
     };

@@ -317,6 +317,16 @@ struct Frame {
         float t = fma_(kf, dt, t0);
         if (!(t < far)) break;
         V3 ip = madd3(ipos, t, idir);
+        if (p.dvr_skip_empty && v.skip_bits) {  // exact skipping: alpha would be exactly 0
+          int cx = f2i(floorf(ip.x - 0.5f)) + 1, cy = f2i(floorf(ip.y - 0.5f)) + 1, cz = f2i(floorf(ip.z - 0.5f)) + 1;
+          uint32_t sh = 3u + v.skip_level;
+          if (cx >= 0 && cy >= 0 && cz >= 0 && ((uint32_t)cx >> sh) < v.skip_dims[0] &&
+              ((uint32_t)cy >> sh) < v.skip_dims[1] && ((uint32_t)cz >> sh) < v.skip_dims[2] &&
+              skip_test(v.skip_bits, sh, v.skip_dims[0], v.skip_dims[1], (uint32_t)cx, (uint32_t)cy, (uint32_t)cz)) {
+            c.skips++;
+            continue;
+          }
+        }
         float4 rgba = transfer(trilinear(ip) * p.volume_inv_maj);
         c.samples++;
         if (rgba.w > 0.0f) {

@@ -135,7 +135,7 @@ class Volxel3DDicomRenderer {
       densityMultiplier: 1, maxSamples: 2000, debugHits: false, volumeClipMin: [0, 0, 0], volumeClipMax: [1, 1, 1],
       showEnvironment: true, useEnv: true, lightDir: [-1, -1, -1].map(v => v / Math.sqrt(3)), syncLightDir: false,
       bounces: 3, gamma: 2.2, exposure: 5.5, sampleRange: [0, 1], renderMode: 'default', resolutionFactor: 1,
-      dvrStepVoxels: 0.5, dvrErtEpsilon: 1e-4, dvrJitter: false, dvrMaxSteps: 1 << 20, phong: [0.3, 0.7, 0.4, 32],
+      dvrStepVoxels: 0.5, dvrErtEpsilon: 1e-4, dvrJitter: false, dvrMaxSteps: 1 << 20, dvrSkipEmpty: true, phong: [0.3, 0.7, 0.4, 32],
     };
     this.camera = new Camera(1);                  // viewer.ts:418
     this.envStrength = 1;
@@ -226,7 +226,7 @@ class Volxel3DDicomRenderer {
     p.set('res', [this.width, this.height]); p.set('debug_hits', s.debugHits ? 1 : 0);
     p.set('render_mode', RenderMode[s.renderMode]);
     p.set('dvr_step_voxels', s.dvrStepVoxels); p.set('dvr_ert_tau', -Math.log(s.dvrErtEpsilon));
-    p.set('dvr_jitter', s.dvrJitter ? 1 : 0); p.set('dvr_max_steps', s.dvrMaxSteps);
+    p.set('dvr_jitter', s.dvrJitter ? 1 : 0); p.set('dvr_max_steps', s.dvrMaxSteps); p.set('dvr_skip_empty', s.dvrSkipEmpty ? 1 : 0);
     const f = Math.fround;
     const fp = f(f(1) / f(f(4) * f(Math.PI)));                         // utils.glsl:121-124, g = 0
     const mis = s.showEnvironment ? f(f(1) / f(f(1) + f(fp * fp))) : f(1); // utils.glsl:104

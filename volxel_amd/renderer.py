@@ -89,6 +89,7 @@ def compute_params(settings: ViewerSettings, camera: Camera, volume: Volume, den
     p.dvr_ert_tau = -math.log(settings.dvr_ert_epsilon)
     p.dvr_jitter = 1 if settings.dvr_jitter else 0
     p.dvr_max_steps = int(settings.dvr_max_steps)
+    p.dvr_skip_empty = 1 if settings.dvr_skip_empty else 0
     # K = albedo * mis * f_p * Le / pdf for the directional light (fragment.frag:94-97,
     # environment.glsl:30-33, utils.glsl:104,121-124), in float32 like the shader
     f32 = np.float32

@@ -33,6 +33,7 @@ class ViewerSettings:  # settings.ts:45-61, defaults viewer.ts:147-163
     dvr_ert_epsilon: float = 1e-4
     dvr_jitter: bool = False
     dvr_max_steps: int = 1 << 20
+    dvr_skip_empty: bool = True   # exact empty-space skipping (samples with alpha == 0 for sure)
     phong: tuple = (0.3, 0.7, 0.4, 32.0)  # ka, kd, ks, shininess
 
 
