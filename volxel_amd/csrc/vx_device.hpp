@@ -64,6 +64,14 @@ VXD int f2i(float x) {
   return r;
 }
 
+// a*b + c on 24-bit unsigned operands: one full-rate v_mad_u32_u24 (hipcc otherwise picks the
+// quarter-rate v_mad_u64_u32 for 32-bit index arithmetic)
+VXD uint32_t mad24(uint32_t a, uint32_t b, uint32_t c) {
+  uint32_t r;
+  asm("v_mad_u32_u24 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(c));
+  return r;
+}
+
 struct V3 {
   float x, y, z;
 };

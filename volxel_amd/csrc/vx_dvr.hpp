@@ -151,13 +151,15 @@ __global__ __launch_bounds__(256) void render_dvr_cq(const VxParams p, const Dev
         }
       }
       ok[u] = eval;
-      uint32_t b = ((cz >> 3) * cby + (cy >> 3)) * cbx + (cx >> 3);
+      // quad index in 32 bits (24-bit multiplies; < 2^32 quads = 64 GiB), one 64-bit shift-add
+      uint32_t b = mad24(mad24(cz >> 3, cby, cy >> 3), cbx, cx >> 3);
       uint32_t cell = ((cz & 7u) << 6) | ((cy & 7u) << 3) | (cx & 7u);
       // unconditional loads (finished / skipped lanes read quad 0): no control flow between the
       // 2*U gathers, so they are all in flight before the first s_waitcnt
-      size_t o = eval ? ((size_t)b * CQ_BRICK_QUADS + cell) : (size_t)0;
-      q0[u] = cq[o];
-      q1[u] = cq[o + CQ_SLICE_QUADS];
+      uint32_t o = eval ? mad24(b, CQ_BRICK_QUADS, cell) : 0u;  // b < 2^24 bricks
+      const float4* qp = cq + o;
+      q0[u] = qp[0];
+      q1[u] = qp[CQ_SLICE_QUADS];
     }
     // ---- phase 2: interpolate, classify, composite in order -----------------------------------
 #pragma unroll
