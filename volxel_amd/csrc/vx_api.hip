@@ -64,6 +64,8 @@ struct VxContext {
   // counters / timing
   DevCounters* dc = nullptr;   // one record per wave of the largest launch grid
   size_t dc_waves = 0;
+  uint32_t* order = nullptr;   // launch permutation of the DVR kernel (build_order), dc_waves/4 entries
+  bool use_order = true;
   VxCounters base{};           // totals folded in when the record array is reallocated
   std::vector<EventPair> free_events, pending_events;
   double kernel_ms = 0.0, last_kernel_ms = 0.0;
@@ -276,6 +278,14 @@ static int ensure_counters(VxContext* c, size_t waves) {
   VX_HIP(c, hipMalloc(&c->dc, waves * sizeof(DevCounters)));
   VX_HIP(c, hipMemset(c->dc, 0, waves * sizeof(DevCounters)));
   c->dc_waves = waves;
+  if (c->order) (void)hipFree(c->order);
+  c->order = nullptr;
+  {
+    std::vector<uint32_t> ident(waves / 4);
+    for (size_t i = 0; i < ident.size(); ++i) ident[i] = (uint32_t)i;
+    VX_HIP(c, hipMalloc(&c->order, ident.size() * 4));
+    VX_HIP(c, hipMemcpy(c->order, ident.data(), ident.size() * 4, hipMemcpyHostToDevice));
+  }
   return VX_OK;
 }
 
@@ -320,6 +330,8 @@ int vx_create(int device_id, VxContext** out) {
   c->stream = c->own_stream;
   const char* v = getenv("VX_DVR_KERNEL");
   if (v && !strcmp(v, "generic")) c->dvr_variant = 0;
+  const char* o = getenv("VX_DVR_ORDER");
+  if (o && !strcmp(o, "0")) c->use_order = false;
   *out = c;
   return VX_OK;
 }
@@ -340,6 +352,7 @@ void vx_destroy(VxContext* c) {
   if (c->image) (void)hipFree(c->image);
   if (c->display) (void)hipFree(c->display);
   if (c->dc) (void)hipFree(c->dc);
+  if (c->order) (void)hipFree(c->order);
   if (c->own_stream) (void)hipStreamDestroy(c->own_stream);
   delete c;
 }
@@ -571,7 +584,7 @@ int vx_render_frame(VxContext* c, uint32_t frame_index, float sample_weight) {
                     c->dc, c->stream);
   } else if (tuned) {
     launch_dvr_cq(c->params, c->dv, c->tf, c->tf_len, c->slab, frame_index, sample_weight, c->tm,
-                  c->dc, c->stream, c->prop.multiProcessorCount);
+                  c->dc, c->stream, c->use_order ? c->order : nullptr);
   } else {
     switch (mode) {
       case VX_MODE_DEFAULT: launch_generic<VX_MODE_DEFAULT>(c, frame_index, sample_weight, grid, lds); break;
@@ -583,6 +596,10 @@ int vx_render_frame(VxContext* c, uint32_t frame_index, float sample_weight) {
   }
   hipError_t le = hipGetLastError();
   VX_HIP(c, hipEventRecord(ev.b, c->stream));
+  if (tuned && c->layout == VX_LAYOUT_CELLQUAD && c->use_order && le == hipSuccess) {
+    hipLaunchKernelGGL(build_order, dim3(1), dim3(1024), 0, c->stream, c->dc, c->order, grid.x);
+    le = hipGetLastError();
+  }
   c->pending_events.push_back(ev);
   c->launches++;
   if (le != hipSuccess) VX_FAIL(c, VX_ERR_DEVICE, "render kernel launch: %s", hipGetErrorString(le));

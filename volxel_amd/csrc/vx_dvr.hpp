@@ -77,15 +77,18 @@ __global__ __launch_bounds__(256) void render_dvr_cq(const VxParams p, const Dev
                                                       const float4* __restrict__ tf_global,
                                                       uint32_t tf_len, float4* __restrict__ slab,
                                                       uint32_t frame, float weight, const TileMap tm,
-                                                      DevCounters* __restrict__ dc) {
+                                                      DevCounters* __restrict__ dc,
+                                                      const uint32_t* __restrict__ order) {
   extern __shared__ float4 tf_lds[];
   uint32_t* mask_lds = reinterpret_cast<uint32_t*>(tf_lds + tf_len);
   for (uint32_t i = threadIdx.x; i < tf_len; i += blockDim.x) tf_lds[i] = tf_global[i];
   if (SKIP)
     for (uint32_t i = threadIdx.x; i < v.skip_words; i += blockDim.x) mask_lds[i] = v.skip_bits[i];
   __syncthreads();
+  // launch slot -> logical block (longest-first order of the previous frame, same XCD class)
+  const uint32_t blk = order ? order[blockIdx.x] : blockIdx.x;
   uint32_t lt, sub;
-  if (!block_to_tile(blockIdx.x, tm, lt, sub)) return;
+  if (!block_to_tile(blk, tm, lt, sub)) return;
   const uint32_t wt = sub * 4u + (threadIdx.x >> 6), lane = threadIdx.x & 63u;
   int px, py;
   uint32_t si;
@@ -219,19 +222,19 @@ __global__ __launch_bounds__(256) void render_dvr_cq(const VxParams p, const Dev
 
   if (in_image) dvr_store(p, r, Cx, Cy, Cz, T, weight, slab, si);
   const uint32_t n_px = (uint32_t)__builtin_popcountll(__ballot(in_image));
-  add_counts(dc, n_samples, n_rays, n_px, n_skipped, 0u, n_slots);
+  add_counts(dc, n_samples, n_rays, n_px, n_skipped, 0u, n_slots, blk);
 }
 
 inline void launch_dvr_cq(const VxParams& p, const DevVolume& v, const float4* tf, uint32_t tf_len,
                           float4* slab, uint32_t frame, float weight, const TileMap& tm,
-                          DevCounters* dc, hipStream_t stream, int /*n_cus*/) {
+                          DevCounters* dc, hipStream_t stream, const uint32_t* order) {
   uint32_t groups = (tm.tiles_per_shard + 7u) / 8u;
   static const int unroll = [] { const char* e = getenv("VX_DVR_UNROLL"); return e ? atoi(e) : 4; }();
   dim3 grid(groups * 128u), block(256);
   const bool skip = p.dvr_skip_empty && v.skip_bits;
   size_t lds = (size_t)tf_len * sizeof(float4) + (skip ? (size_t)v.skip_words * 4u : 0u);
 #define VX_LAUNCH(UU, SS) \
-  hipLaunchKernelGGL((render_dvr_cq<UU, SS>), grid, block, lds, stream, p, v, tf, tf_len, slab, frame, weight, tm, dc)
+  hipLaunchKernelGGL((render_dvr_cq<UU, SS>), grid, block, lds, stream, p, v, tf, tf_len, slab, frame, weight, tm, dc, order)
   if (skip) {
     switch (unroll) {
       case 1: VX_LAUNCH(1, true); break;

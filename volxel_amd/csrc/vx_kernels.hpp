@@ -52,13 +52,18 @@ VXD uint32_t wave_sum(uint32_t x) {
 struct DevCounters {
   unsigned long long samples, slots;
   uint32_t rays, pixels, skips, grads;
+  uint32_t last_slots;  // lane slots of the most recent launch: the cost fed back to build_order
+  uint32_t pad;
 };
 
+// `block` = logical block id (identical to blockIdx.x unless the launch is permuted by `order`)
 VXD void add_counts(DevCounters* dc, uint32_t samples, uint32_t rays, uint32_t pixels, uint32_t skips,
-                    uint32_t grads, uint32_t slots) {
+                    uint32_t grads, uint32_t slots, uint32_t block = 0xffffffffu) {
   if ((threadIdx.x & 63u) == 0) {
-    DevCounters* w = dc + (blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6));
+    if (block == 0xffffffffu) block = blockIdx.x;
+    DevCounters* w = dc + (block * (blockDim.x >> 6) + (threadIdx.x >> 6));
     DevCounters c = *w;
+    c.last_slots = slots;
     c.samples += samples;
     c.slots += slots;
     c.rays += rays;
@@ -116,6 +121,43 @@ __global__ __launch_bounds__(256) void render_generic(const VxParams p, const De
     slab[si] = o;
   }
   flush_counts(dc, c, active ? 1u : 0u);
+}
+
+// ---- longest-processing-time-first launch order, fed back from the previous frame ------------
+// The march is latency-bound on the longest rays: one wave that walks the whole volume needs
+// ~0.35 ms even on an idle GPU, so it must start first.  Progressive rendering repeats the same
+// view, so the per-wave step counts of frame f are the cost estimate for frame f+1.  Blocks keep
+// their XCD class (b % 8, see block_to_tile): within each class they are ranked by the longest of
+// their four waves (counting sort, 64 buckets of 32 steps), and launch slot pos*8+x runs the
+// pos-th longest block of class x.  Any permutation yields the same image; a stale order after a
+// camera change only costs speed for one frame.  One workgroup, runs after every DVR frame.
+__global__ __launch_bounds__(1024) void build_order(const DevCounters* __restrict__ dc,
+                                                     uint32_t* __restrict__ order, uint32_t n_blocks) {
+  __shared__ uint32_t hist[8][64];
+  for (uint32_t i = threadIdx.x; i < 8 * 64; i += blockDim.x) (&hist[0][0])[i] = 0;
+  __syncthreads();
+  auto bucket_of = [&](uint32_t b) {
+    const DevCounters* w = dc + (size_t)b * 4u;
+    uint32_t c = max(max(w[0].last_slots, w[1].last_slots), max(w[2].last_slots, w[3].last_slots));
+    uint32_t k = c >> 11;  // slots / 64 lanes / 32 steps
+    return 63u - (k > 63u ? 63u : k);  // bucket 0 = longest
+  };
+  for (uint32_t b = threadIdx.x; b < n_blocks; b += blockDim.x) atomicAdd(&hist[b & 7u][bucket_of(b)], 1u);
+  __syncthreads();
+  if (threadIdx.x < 8) {  // exclusive prefix per class
+    uint32_t acc = 0;
+    for (int k = 0; k < 64; ++k) {
+      uint32_t h = hist[threadIdx.x][k];
+      hist[threadIdx.x][k] = acc;
+      acc += h;
+    }
+  }
+  __syncthreads();
+  for (uint32_t b = threadIdx.x; b < n_blocks; b += blockDim.x) {
+    uint32_t x = b & 7u;
+    uint32_t pos = atomicAdd(&hist[x][bucket_of(b)], 1u);
+    order[pos * 8u + x] = b;
+  }
 }
 
 // ---- reference layout -> cellquad (runs once per upload) -------------------------------
