@@ -50,6 +50,7 @@ def build_scene(width, height, n_vox, rank, world, device):
     r.settings.volume_clip_max = (1.0, 1.0, 0.75)
     r.settings.dvr_step_voxels = 0.5
     r.settings.dvr_ert_epsilon = 1e-4
+    r.settings.dvr_skip_empty = False   # BASELINE config 3 is ERT + clip box; skipping is reported aside
     r.settings.max_samples = 1 << 30
     t3 = time.time()
     nb = int(np.prod(msg.indirection_size))
@@ -79,6 +80,21 @@ def cpu_baseline(r, msg, crop=(1920, 1080)):
             "ms_per_frame_crop": round(dt * 1e3, 1)}
 
 
+def traffic_from_profile(a):
+    """HBM bytes per launch from the rocprofv3 PMC passes of this same command (collected by
+    tools/pmc_profile.sh, summarised into profiles/traffic.json): 2 x FETCH_SIZE (gfx950 reports
+    half of the fetched bytes, MI355X_MICROARCH.md section HBM) + WRITE_SIZE, in bytes."""
+    path = os.path.join(ROOT, "profiles", "traffic.json")
+    key = {None: "cellquad", 0: "reference", 1: "cellquad", 2: "brickf32"}[a.layout]
+    try:
+        t = json.load(open(path))[key]
+        if (t["width"], t["height"], t["volume"]) != (a.width, a.height, a.volume):
+            return {"traffic": None}
+        return {"traffic": int(t["hbm_bytes_per_launch"]), "traffic_source": t["source"]}
+    except Exception:
+        return {"traffic": None}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -91,6 +107,7 @@ def main():
     ap.add_argument("--layout", type=int, default=None, help="0 reference, 1 cellquad (default), 2 brickf32 + LDS tiles")
     ap.add_argument("--gather-every", type=int, default=8,
                     help="N>1: all_gather the framebuffer once per this many accumulation frames")
+    ap.add_argument("--no-skip-variant", action="store_true", help="do not run the secondary measurement with skipping")
     ap.add_argument("--force-gather", action="store_true", help="run the gather path with one rank too (testing)")
     a = ap.parse_args()
 
@@ -221,7 +238,7 @@ def main():
             },
             "roofline": {
                 "bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": None,
+                "frac": round(achieved / HBM_PEAK_GBS, 4), **traffic_from_profile(a),
                 "kernel": {None: "vx::render_dvr_cq<4>", 0: "vx::render_generic<3,0>", 1: "vx::render_dvr_cq<4>", 2: "vx::render_dvr_tile<8>"}[a.layout],
                 "avg_kernel_ms": round(c.kernel_ms / launches, 4),
                 "algorithmic_bytes_per_launch": int(alg_bytes_launch),
@@ -232,6 +249,18 @@ def main():
             out["cpu_baseline"] = cpu_baseline(r, msg)
         else:
             out["cpu_baseline"] = None
+        if world == 1 and not a.no_skip_variant:
+            # same frame with the exact empty-space skipping switched on (fewer samples are
+            # evaluated, so the headline metric above is quoted without it)
+            r.settings.dvr_skip_empty = True
+            r.bind_uniforms()
+            r.render(frames=5, rebind=False); r.finish(); r.reset_counters()
+            r.render(frames=20, rebind=False); r.finish()
+            cs = r.counters()
+            out["config"]["with_empty_space_skipping"] = {
+                "ms_per_frame": round(cs.kernel_ms / cs.launches, 4),
+                "samples_per_frame": int(cs.samples // cs.launches),
+                "gsamples_per_s": round(cs.samples / cs.kernel_ms / 1e6, 1)}
         real_stdout.write(json.dumps(out) + "\n")
         real_stdout.flush()
     if use_dist:

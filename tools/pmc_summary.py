@@ -10,7 +10,11 @@ from collections import defaultdict
 
 root, kern = sys.argv[1], sys.argv[2]
 print(f"# rocprofv3 summary for kernels matching '{kern}' under {root}")
-for f in glob.glob(os.path.join(root, "kt", "**", "*kernel_stats.csv"), recursive=True):
+def newest(pattern):
+    fs = glob.glob(pattern, recursive=True)
+    return [max(fs, key=os.path.getmtime)] if fs else []
+
+for f in newest(os.path.join(root, "kt", "**", "*kernel_stats.csv")):
     print("\n## kernel-trace --stats (" + os.path.relpath(f, root) + ")")
     print(open(f).read().strip())
 bj = os.path.join(root, "bench_kt.json")
@@ -22,7 +26,7 @@ for d in sorted(glob.glob(os.path.join(root, "*"))):
     if name == "kt" or not os.path.isdir(d):
         continue
     acc = defaultdict(list)
-    for f in glob.glob(os.path.join(d, "**", "*counter_collection.csv"), recursive=True):
+    for f in newest(os.path.join(d, "**", "*counter_collection.csv")):
         for row in csv.DictReader(open(f)):
             if kern in row.get("Kernel_Name", ""):
                 acc[row["Counter_Name"]].append(float(row["Counter_Value"]))

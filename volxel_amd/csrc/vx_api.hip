@@ -66,6 +66,7 @@ struct VxContext {
   size_t dc_waves = 0;
   uint32_t* order = nullptr;   // launch permutation of the DVR kernel (build_order), dc_waves/4 entries
   bool use_order = true;
+  int order_builds_left = 2;   // rebuild the order after the first frames that follow a change
   VxCounters base{};           // totals folded in when the record array is reallocated
   std::vector<EventPair> free_events, pending_events;
   double kernel_ms = 0.0, last_kernel_ms = 0.0;
@@ -285,6 +286,7 @@ static int ensure_counters(VxContext* c, size_t waves) {
     for (size_t i = 0; i < ident.size(); ++i) ident[i] = (uint32_t)i;
     VX_HIP(c, hipMalloc(&c->order, ident.size() * 4));
     VX_HIP(c, hipMemcpy(c->order, ident.data(), ident.size() * 4, hipMemcpyHostToDevice));
+    c->order_builds_left = 2;
   }
   return VX_OK;
 }
@@ -450,6 +452,7 @@ int vx_upload_volume(VxContext* c, const uint32_t* indirection, const uint32_t i
   c->dv.range = (const uint32_t*)d;
   c->range_host.assign((const uint32_t*)range, (const uint32_t*)range + nb);
   c->skip_dirty = true;
+  c->order_builds_left = 2;
   if ((rc = up(atlas, atlas_bytes, &d))) return rc;
   c->dv.atlas = (const uint8_t*)d;
   for (int k = 0; k < 3; ++k) {
@@ -498,6 +501,7 @@ int vx_upload_transfer(VxContext* c, const float* rgba, uint32_t length) {
   c->tf_len = length;
   c->tf_host.assign(rgba, rgba + (size_t)length * 4);
   c->skip_dirty = true;
+  c->order_builds_left = 2;
   return VX_OK;
 }
 
@@ -517,6 +521,7 @@ int vx_set_params(VxContext* c, const VxParams* p) {
     VX_FAIL(c, VX_ERR_INVALID, "vx_set_params: dvr_step_voxels must be > 0");
   bool reshard = !c->has_params || p->shard_count != c->params.shard_count ||
                  p->shard_rank != c->params.shard_rank;
+  if (!c->has_params || memcmp(&c->params, p, sizeof(VxParams)) != 0) c->order_builds_left = 2;
   c->params = *p;
   c->has_params = true;
   if (reshard && c->W) {
@@ -596,7 +601,8 @@ int vx_render_frame(VxContext* c, uint32_t frame_index, float sample_weight) {
   }
   hipError_t le = hipGetLastError();
   VX_HIP(c, hipEventRecord(ev.b, c->stream));
-  if (tuned && c->layout == VX_LAYOUT_CELLQUAD && c->use_order && le == hipSuccess) {
+  if (tuned && c->layout == VX_LAYOUT_CELLQUAD && c->use_order && le == hipSuccess && c->order_builds_left > 0) {
+    c->order_builds_left--;
     hipLaunchKernelGGL(build_order, dim3(1), dim3(1024), 0, c->stream, c->dc, c->order, grid.x);
     le = hipGetLastError();
   }
