@@ -72,6 +72,8 @@ struct VxContext {
   double kernel_ms = 0.0, last_kernel_ms = 0.0;
   uint64_t launches = 0;
   int dvr_variant = -1;  // -1: tuned kernel; 0: generic
+  int dp_env = -1;       // VX_DVR_DP=1: depth-parallel waves (experiment, see vx_dvr.hpp)
+  bool dp_active() const { return dp_env == 1; }
 };
 
 #define VX_FAIL(ctx, code, ...)                       \
@@ -332,6 +334,8 @@ int vx_create(int device_id, VxContext** out) {
   c->stream = c->own_stream;
   const char* v = getenv("VX_DVR_KERNEL");
   if (v && !strcmp(v, "generic")) c->dvr_variant = 0;
+  const char* dpe = getenv("VX_DVR_DP");
+  if (dpe) c->dp_env = atoi(dpe);
   const char* o = getenv("VX_DVR_ORDER");
   if (o && !strcmp(o, "0")) c->use_order = false;
   *out = c;
@@ -576,7 +580,7 @@ int vx_render_frame(VxContext* c, uint32_t frame_index, float sample_weight) {
   uint32_t groups = (c->tm.tiles_per_shard + 7u) / 8u;
   dim3 grid(groups * 128u);
   {
-    int rc = ensure_counters(c, (size_t)grid.x * 4u);
+    int rc = ensure_counters(c, (size_t)grid.x * 4u * 8u);  // x8: the depth-parallel DVR grid
     if (rc) return rc;
   }
   size_t lds = c->tf_len <= TF_LDS_MAX ? (size_t)c->tf_len * sizeof(float4) : 0;
@@ -589,7 +593,7 @@ int vx_render_frame(VxContext* c, uint32_t frame_index, float sample_weight) {
                     c->dc, c->stream);
   } else if (tuned) {
     launch_dvr_cq(c->params, c->dv, c->tf, c->tf_len, c->slab, frame_index, sample_weight, c->tm,
-                  c->dc, c->stream, c->use_order ? c->order : nullptr);
+                  c->dc, c->stream, (c->use_order && !c->dp_active()) ? c->order : nullptr);
   } else {
     switch (mode) {
       case VX_MODE_DEFAULT: launch_generic<VX_MODE_DEFAULT>(c, frame_index, sample_weight, grid, lds); break;
@@ -601,7 +605,7 @@ int vx_render_frame(VxContext* c, uint32_t frame_index, float sample_weight) {
   }
   hipError_t le = hipGetLastError();
   VX_HIP(c, hipEventRecord(ev.b, c->stream));
-  if (tuned && c->layout == VX_LAYOUT_CELLQUAD && c->use_order && le == hipSuccess && c->order_builds_left > 0) {
+  if (tuned && c->layout == VX_LAYOUT_CELLQUAD && c->use_order && !c->dp_active() && le == hipSuccess && c->order_builds_left > 0) {
     c->order_builds_left--;
     hipLaunchKernelGGL(build_order, dim3(1), dim3(1024), 0, c->stream, c->dc, c->order, grid.x);
     le = hipGetLastError();

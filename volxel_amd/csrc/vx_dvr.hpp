@@ -225,10 +225,233 @@ __global__ __launch_bounds__(256) void render_dvr_cq(const VxParams p, const Dev
   add_counts(dc, n_samples, n_rays, n_px, n_skipped, 0u, n_slots, blk);
 }
 
+VXD int wave_min_i32(int v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) {
+    int w = __shfl_xor(v, o, 64);
+    v = w < v ? w : v;
+  }
+  return v;
+}
+
+// ---------------------------------------------------------------------------------------------
+// Depth-parallel variant: one wave = 8 rays (an 8x1 pixel row) x 8 consecutive march steps.
+//
+// Why: the 8x8-pixel kernel above keeps 64 rays in lock step, so a wave that looks through the
+// whole clip box runs ~1500 dependent iterations (~0.35 ms even on an idle GPU).  That chain is the
+// floor of the frame time and it does not shrink when the image is sharded over more GPUs
+// (tools/shard_probe.py: 1.9x at 8 shards).  Here lane (r, j) evaluates step kb+j of ray r: the 64
+// samples of an iteration are 8 steps of 8 rays, the longest chain is 8x shorter and there are 8x
+// more waves to spread.  Density, TF and alpha of the 8 steps are independent; only the optical
+// depth is a recurrence, tau_k = fma(alpha_k*maj, dt, tau_{k-1}).  It is evaluated in EXACTLY that
+// order with an 8-step DPP chain (row_shr:1 + fma), so tau, the termination decision and the
+// sample count stay bit-identical to the sequential oracle; the colour sum is re-associated
+// (per-lane partial sums, reduced once per ray: differences ~1e-7, no decision depends on it).
+VXD float dpp_shr1(float v) {
+  return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x111, 0xf, 0xf, false));
+}
+template <int SH>
+VXD float dpp_shr(float v) {
+  return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x110 + SH, 0xf, 0xf, false));
+}
+
+// block b -> (local tile, wave-tile, half): 128 blocks per 64x64 tile, whole tiles round-robin over XCDs
+VXD bool block_to_tile_dp(uint32_t b, const TileMap& tm, uint32_t& lt, uint32_t& wt, uint32_t& half) {
+  lt = (b >> 10) * 8u + (b & 7u);
+  uint32_t sub = (b >> 3) & 127u;
+  wt = sub >> 1;
+  half = sub & 1u;
+  return lt < tm.tiles_per_shard;
+}
+
+template <bool SKIP>
+__global__ __launch_bounds__(256) void render_dvr_dp(const VxParams p, const DevVolume v,
+                                                      const float4* __restrict__ tf_global,
+                                                      uint32_t tf_len, float4* __restrict__ slab,
+                                                      uint32_t frame, float weight, const TileMap tm,
+                                                      DevCounters* __restrict__ dc) {
+  extern __shared__ float4 tf_lds[];
+  uint32_t* mask_lds = reinterpret_cast<uint32_t*>(tf_lds + tf_len);
+  for (uint32_t i = threadIdx.x; i < tf_len; i += blockDim.x) tf_lds[i] = tf_global[i];
+  if (SKIP)
+    for (uint32_t i = threadIdx.x; i < v.skip_words; i += blockDim.x) mask_lds[i] = v.skip_bits[i];
+  __syncthreads();
+  uint32_t lt, wt, half;
+  if (!block_to_tile_dp(blockIdx.x, tm, lt, wt, half)) return;
+  const uint32_t lane = threadIdx.x & 63u;
+  const uint32_t j = lane & 7u, ray = lane >> 3;            // depth slot, ray of this wave
+  const uint32_t row = half * 4u + (threadIdx.x >> 6);      // pixel row inside the 8x8 wave tile
+  const bool j0 = j == 0u;
+  int px = 0, py = 0;
+  uint32_t si = 0;
+  bool in_image;
+  {
+    uint32_t t = lt * tm.shard_count + tm.shard_rank;
+    si = (lt * 64u + wt) * 64u + row * 8u + ray;
+    in_image = t < tm.n_tiles;
+    if (in_image) {
+      uint32_t tx = t % tm.tiles_x, ty = t / tm.tiles_x;
+      px = (int)(tx * 64u + morton_x(wt) * 8u + ray);
+      py = (int)(ty * 64u + morton_x(wt >> 1) * 8u + row);
+      in_image = (uint32_t)px < tm.W && (uint32_t)py < tm.H;
+    }
+  }
+  DvrRay r{};
+  if (in_image) r = dvr_setup(p, px, py, frame);   // the 8 lanes of a ray compute the same setup
+  bool ray_alive = in_image && r.hit;
+  const uint32_t n_rays = (uint32_t)__builtin_popcountll(__ballot(ray_alive && j0));
+
+  const float scale = p.volume_density_scale, inv_maj = p.volume_inv_maj, maj = p.volume_maj;
+  const float sr0 = p.sample_range[0], sr1 = p.sample_range[1];
+  const float lenf = (float)tf_len;
+  const int last = (int)tf_len - 1;
+  const uint32_t cbx = v.cq_bc[0], cby = v.cq_bc[1];
+  const float4* __restrict__ cq = v.cq;
+  const uint32_t cmaxx = v.extent[0] + 7u, cmaxy = v.extent[1] + 7u, cmaxz = v.extent[2] + 7u;
+  const float ert = p.dvr_ert_tau;
+  const float max_steps_f = (float)p.dvr_max_steps;
+  const uint32_t sh = 3u + v.skip_level, md0 = v.skip_dims[0], md1 = v.skip_dims[1];
+  const float inv_dt = SKIP ? 1.0f / r.dt : 0.0f;
+  const float jf = (float)j;
+
+  float Cx = 0.f, Cy = 0.f, Cz = 0.f;   // per-lane partial colour sums
+  float carry = 0.0f;                    // optical depth of the ray before this iteration's 8 steps
+  float kb = 0.0f;                       // wave-uniform base step of the iteration
+  uint32_t n_samples = 0, n_slots = 0, n_skipped = 0;
+
+  while (true) {
+    {
+      float t = fma_(kb, r.dt, r.t0);    // first step of the group decides whether the ray goes on
+      ray_alive = ray_alive && (t < r.far) && (kb < max_steps_f);
+      if (__ballot(ray_alive) == 0ull) break;
+    }
+    const float k = kb + jf;
+    const float t = fma_(k, r.dt, r.t0);
+    const bool in = ray_alive && (t < r.far) && (k < max_steps_f);
+    // A5 on the cellquad layout (as render_dvr_cq)
+    float qx = fma_(t, r.idir.x, r.ipos.x) - 0.5f;
+    float qy = fma_(t, r.idir.y, r.ipos.y) - 0.5f;
+    float qz = fma_(t, r.idir.z, r.ipos.z) - 0.5f;
+    float flx = floorf(qx), fly = floorf(qy), flz = floorf(qz);
+    float fx = qx - flx, fy = qy - fly, fz = qz - flz;
+    uint32_t cx = (uint32_t)((int)flx + 1), cy = (uint32_t)((int)fly + 1), cz = (uint32_t)((int)flz + 1);
+    cx = cx < cmaxx ? cx : cmaxx; cy = cy < cmaxy ? cy : cmaxy; cz = cz < cmaxz ? cz : cmaxz;
+    bool eval = in, empty = false;
+    if (SKIP) {
+      uint32_t mi = ((cz >> sh) * md1 + (cy >> sh)) * md0 + (cx >> sh);
+      empty = (mask_lds[mi >> 5] >> (mi & 31u)) & 1u;
+      eval = in && !empty;
+    }
+    uint32_t b = mad24(mad24(cz >> 3, cby, cy >> 3), cbx, cx >> 3);
+    uint32_t cell = ((cz & 7u) << 6) | ((cy & 7u) << 3) | (cx & 7u);
+    uint32_t o = eval ? mad24(b, CQ_BRICK_QUADS, cell) : 0u;
+    const float4* qp = cq + o;
+    float4 q0 = qp[0];
+    float4 q1 = qp[CQ_SLICE_QUADS];
+    float wx = 1.0f - fx, wy = 1.0f - fy, wz = 1.0f - fz;
+    float lx0 = fma_(q0.y, fx, q0.x * wx);
+    float lx1 = fma_(q0.w, fx, q0.z * wx);
+    float hx0 = fma_(q1.y, fx, q1.x * wx);
+    float hx1 = fma_(q1.w, fx, q1.z * wx);
+    float l = fma_(lx1, fy, lx0 * wy);
+    float h = fma_(hx1, fy, hx0 * wy);
+    float d = scale * fma_(h, fz, l * wz);
+    float dn = d * inv_maj;
+    int ti = (int)(dn * lenf);
+    ti = ti > last ? last : ti;
+    ti = ti < 0 ? 0 : ti;
+    bool in_range = !(dn < sr0 || dn > sr1);
+    float4 rgba = tf_lds[ti];
+    float alpha = (eval && in_range) ? rgba.w : 0.0f;
+    // ---- exact sequential optical depth over the ray's 8 steps (DPP chain) --------------------
+    const float x = alpha * maj;
+    float tau = carry;
+#pragma unroll
+    for (int s = 0; s < 8; ++s) {
+      float prev = dpp_shr1(tau);
+      prev = j0 ? carry : prev;
+      tau = fma_(x, r.dt, prev);       // alpha == 0: tau = prev exactly
+    }
+    float tau_prev = dpp_shr1(tau);
+    tau_prev = j0 ? carry : tau_prev;
+    // a step counts (and contributes) while the ray had not terminated before it
+    const bool valid = eval && (tau_prev < ert);
+    {
+      unsigned long long m = __ballot(valid);
+      n_samples += (uint32_t)__builtin_popcountll(m);
+      n_slots += m ? 64u : 0u;
+      if (SKIP) n_skipped += (uint32_t)__builtin_popcountll(__ballot(in && empty && (tau_prev < ert)));
+    }
+    if (__ballot(valid && alpha > 0.0f) != 0ull) {
+      float Tn = __builtin_amdgcn_exp2f(tau * -1.4426950408889634f);
+      float Tp = __builtin_amdgcn_exp2f(tau_prev * -1.4426950408889634f);
+      float dT = (valid && alpha > 0.0f) ? Tp - Tn : 0.0f;
+      Cx = fma_(dT, rgba.x, Cx);
+      Cy = fma_(dT, rgba.y, Cy);
+      Cz = fma_(dT, rgba.z, Cz);
+    }
+    // carry = tau of the ray's last slot (monotone, so it also tells whether the ray terminated)
+    carry = __shfl(tau, (int)(lane | 7u), 64);
+    ray_alive = ray_alive && (carry < ert);
+    kb += 8.0f;
+    if (SKIP) {
+      // all live rays ended this group in an empty macro cell: advance every ray by the smallest
+      // safe jump of their last slots (each last slot knows how far its own macro cell extends)
+      const bool last_slot = (j == 7u);
+      bool can = !ray_alive || !last_slot || (in && empty);
+      if (__ballot(!can) == 0ull && __ballot(ray_alive) != 0ull) {
+        const float Sf = (float)(1u << sh);
+        float bx = (float)((cx >> sh) << sh) - 1.0f, by = (float)((cy >> sh) << sh) - 1.0f,
+              bz = (float)((cz >> sh) << sh) - 1.0f;
+        float dx = r.idir.x > 0.0f ? (bx + Sf - qx) / r.idir.x : (r.idir.x < 0.0f ? (bx - qx) / r.idir.x : 3.0e38f);
+        float dy = r.idir.y > 0.0f ? (by + Sf - qy) / r.idir.y : (r.idir.y < 0.0f ? (by - qy) / r.idir.y : 3.0e38f);
+        float dz = r.idir.z > 0.0f ? (bz + Sf - qz) / r.idir.z : (r.idir.z < 0.0f ? (bz - qz) / r.idir.z : 3.0e38f);
+        float n = floorf(fminf(dx, fminf(dy, dz)) * inv_dt) - 2.0f;
+        n = (ray_alive && last_slot) ? fminf(n, 1048576.0f) : 1048576.0f;
+        int ni = wave_min_i32((int)fmaxf(n, 0.0f));
+        if (ni >= 1) kb += (float)ni;
+      }
+    }
+  }
+
+  // ---- per-ray colour: sum of the 8 lanes' partial sums, lands in slot 7 -----------------------
+#pragma unroll
+  for (int sft = 1; sft < 8; sft <<= 1) {
+    float ax = sft == 1 ? dpp_shr<1>(Cx) : (sft == 2 ? dpp_shr<2>(Cx) : dpp_shr<4>(Cx));
+    float ay = sft == 1 ? dpp_shr<1>(Cy) : (sft == 2 ? dpp_shr<2>(Cy) : dpp_shr<4>(Cy));
+    float az = sft == 1 ? dpp_shr<1>(Cz) : (sft == 2 ? dpp_shr<2>(Cz) : dpp_shr<4>(Cz));
+    bool take = j >= (uint32_t)sft;
+    Cx += take ? ax : 0.0f;
+    Cy += take ? ay : 0.0f;
+    Cz += take ? az : 0.0f;
+  }
+  const bool writer = in_image && j == 7u;
+  if (writer) {
+    float T = (carry >= ert) ? 0.0f : __builtin_amdgcn_exp2f(carry * -1.4426950408889634f);
+    dvr_store(p, r, Cx, Cy, Cz, T, weight, slab, si);
+  }
+  const uint32_t n_px = (uint32_t)__builtin_popcountll(__ballot(writer));
+  add_counts(dc, n_samples, n_rays, n_px, n_skipped, 0u, n_slots);
+}
+
 inline void launch_dvr_cq(const VxParams& p, const DevVolume& v, const float4* tf, uint32_t tf_len,
                           float4* slab, uint32_t frame, float weight, const TileMap& tm,
                           DevCounters* dc, hipStream_t stream, const uint32_t* order) {
   uint32_t groups = (tm.tiles_per_shard + 7u) / 8u;
+  static const int dp = [] { const char* e = getenv("VX_DVR_DP"); return e ? atoi(e) : -1; }();
+  // depth-parallel waves only on request (VX_DVR_DP=1): they cut the longest dependent chain 8x
+  // (8 shards: 0.19 ms instead of 0.28 ms per GPU) but cost ~1.6x the instructions (0.80 vs 0.51 ms
+  // on one GPU) and re-associate the colour sum, which gives up bit-identity across shard counts
+  if (dp == 1) {
+    dim3 grid(groups * 1024u), block(256);
+    const bool skip = p.dvr_skip_empty && v.skip_bits;
+    size_t lds = (size_t)tf_len * sizeof(float4) + (skip ? (size_t)v.skip_words * 4u : 0u);
+    if (skip)
+      hipLaunchKernelGGL((render_dvr_dp<true>), grid, block, lds, stream, p, v, tf, tf_len, slab, frame, weight, tm, dc);
+    else
+      hipLaunchKernelGGL((render_dvr_dp<false>), grid, block, lds, stream, p, v, tf, tf_len, slab, frame, weight, tm, dc);
+    return;
+  }
   static const int unroll = [] { const char* e = getenv("VX_DVR_UNROLL"); return e ? atoi(e) : 4; }();
   dim3 grid(groups * 128u), block(256);
   const bool skip = p.dvr_skip_empty && v.skip_bits;
