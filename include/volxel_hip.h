@@ -184,6 +184,13 @@ int vx_resize(VxContext* ctx, uint32_t width, uint32_t height);
  *      context's stream. */
 int vx_render_frame(VxContext* ctx, uint32_t frame_index, float sample_weight);
 
+/* The same for `count` consecutive accumulation frames (weights[i] = u_sample_weight of frame
+ * first_frame + i), with up to `in_flight` (<= 8) of them rendered concurrently on separate HIP
+ * streams.  Accumulation frames are independent given their index; only the running mean is ordered
+ * and it is applied afterwards, in order -- the accumulator is bit-identical to `count` calls of
+ * vx_render_frame.  [build] no reference counterpart: WebGL2 draws are serialised. */
+int vx_render_frames(VxContext* ctx, uint32_t first_frame, uint32_t count, const float* weights, int in_flight);
+
 /* ---- synchronise: replaces gl.finish() (viewer.ts:1214,1289) */
 int vx_finish(VxContext* ctx);
 

@@ -204,6 +204,28 @@ def test_empty_space_skipping_is_exact(oracle, layout):
     assert counts[0] < counts[1]
 
 
+@pytest.mark.parametrize("mode", ["dvr", "raymarch"])
+def test_pipelined_frames_are_bit_identical(oracle, mode):
+    """vx_render_frames with several frames in flight == the same frames one by one"""
+    from tests.common import make_scene, benchmark_tf, BENCH_CAM
+    from volxel_amd import synth
+    vox, sp = synth.value_noise(32, seed=5, zero_quantile=0.4)
+    g = oracle.BrickGrid(vox, sp)
+    tf, L = benchmark_tf()
+    s, cam, vol, ds, p = make_scene(g, 200, 120, mode, dvr_jitter=True, sample_range=(0.05, 1.0), **BENCH_CAM)
+    out = []
+    for in_flight in (1, 4, 8):
+        r = _renderer(g, tf, L, p, 1)
+        r.settings = s; r.camera = cam
+        r.reset_counters()
+        r.render(frames=3)                       # a few serial frames first
+        r.render(frames=11, in_flight=in_flight)
+        out.append((r.read_accum(), r.counters().samples, r.frame_index))
+    assert out[0][2] == 14
+    for img, n, fi in out[1:]:
+        assert np.array_equal(img, out[0][0]) and n == out[0][1] and fi == 14
+
+
 def test_display_pass_matches_blit(oracle):
     from tests.golden.make_golden import build_case
     grid, tf, L, p, frame = build_case(oracle, "noise32_dvr_clip")

@@ -6,6 +6,7 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from bench import build_scene
 
 skip = bool(int(sys.argv[1])) if len(sys.argv) > 1 else False
+in_flight = int(sys.argv[2]) if len(sys.argv) > 2 else 1
 base = None
 for n in (1, 2, 4, 8):
     worst = 0.0; tot = 0
@@ -14,11 +15,11 @@ for n in (1, 2, 4, 8):
         r.settings.dvr_skip_empty = skip
         r.bind_uniforms()
         r.render(frames=4, rebind=False); r.finish(); r.reset_counters()
-        r.render(frames=12, rebind=False); r.finish()
+        r.render(frames=32, rebind=False, in_flight=in_flight); r.finish()
         c = r.counters()
         ms = c.kernel_ms / c.launches
         worst = max(worst, ms); tot = c.samples / c.launches
         r.close()
     if base is None: base = worst
-    print(json.dumps(dict(skip=skip, shards=n, worst_rank_ms=round(worst, 4), predicted_speedup=round(base / worst, 2),
+    print(json.dumps(dict(skip=skip, in_flight=in_flight, shards=n, worst_rank_ms=round(worst, 4), predicted_speedup=round(base / worst, 2),
                           Msamples_rank=round(tot / 1e6, 1))))

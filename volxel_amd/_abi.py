@@ -100,6 +100,7 @@ def load_library():
         "vx_set_params": ([vp, P(VxParams)], i32),
         "vx_resize": ([vp, u32, u32], i32),
         "vx_render_frame": ([vp, u32, C.c_float], i32),
+        "vx_render_frames": ([vp, u32, u32, P(C.c_float), i32], i32),
         "vx_finish": ([vp], i32),
         "vx_read_accum": ([vp, vp], i32),
         "vx_read_display": ([vp, vp, C.c_float, C.c_float], i32),

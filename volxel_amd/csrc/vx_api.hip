@@ -19,6 +19,7 @@ thread_local std::string g_create_error;
 
 struct EventPair {
   hipEvent_t a, b;
+  uint32_t launches = 1;   // frames covered by this interval (pipelined batches cover several)
 };
 
 }  // namespace
@@ -72,6 +73,20 @@ struct VxContext {
   double kernel_ms = 0.0, last_kernel_ms = 0.0;
   uint64_t launches = 0;
   int dvr_variant = -1;  // -1: tuned kernel; 0: generic
+
+  // frame pipelining (vx_render_frames): independent accumulation frames in flight on their own
+  // streams, each into its own result slab + counter records; blended in order afterwards
+  struct Pipe {
+    hipStream_t stream = nullptr;
+    float4* result = nullptr;
+    DevCounters* dc = nullptr;
+    hipEvent_t done = nullptr;
+    hipEvent_t merged = nullptr;  // recorded on the main stream after this slot's result was blended
+    bool has_merged = false;
+  };
+  std::vector<Pipe> pipes;
+  size_t pipe_quads = 0, pipe_waves = 0;
+  uint32_t pipe_next = 0;
   int dp_env = -1;       // VX_DVR_DP=1: depth-parallel waves (experiment, see vx_dvr.hpp)
   bool dp_active() const { return dp_env == 1; }
 };
@@ -108,7 +123,7 @@ static void drain_events(VxContext* c) {
     float ms = 0.f;
     if (hipEventElapsedTime(&ms, e.a, e.b) == hipSuccess) {
       c->kernel_ms += ms;
-      c->last_kernel_ms = ms;
+      c->last_kernel_ms = ms / (float)(e.launches ? e.launches : 1u);
     }
     c->free_events.push_back(e);
   }
@@ -267,6 +282,21 @@ static int fold_counters(VxContext* c) {
     c->base.grad_samples += w.grads;
   }
   VX_HIP(c, hipMemset(c->dc, 0, c->dc_waves * sizeof(DevCounters)));
+  for (auto& p : c->pipes) {
+    if (!p.dc) continue;
+    VX_HIP(c, hipStreamSynchronize(p.stream));
+    std::vector<DevCounters> hp(c->pipe_waves);
+    VX_HIP(c, hipMemcpy(hp.data(), p.dc, hp.size() * sizeof(DevCounters), hipMemcpyDeviceToHost));
+    for (const auto& w : hp) {
+      c->base.samples += w.samples;
+      c->base.lane_slots += w.slots;
+      c->base.rays += w.rays;
+      c->base.pixels += w.pixels;
+      c->base.skip_steps += w.skips;
+      c->base.grad_samples += w.grads;
+    }
+    VX_HIP(c, hipMemset(p.dc, 0, c->pipe_waves * sizeof(DevCounters)));
+  }
   return VX_OK;
 }
 
@@ -294,16 +324,17 @@ static int ensure_counters(VxContext* c, size_t waves) {
 }
 
 template <int MODE>
-static void launch_generic(VxContext* c, uint32_t frame, float weight, dim3 grid, size_t lds) {
+static void launch_generic(VxContext* c, uint32_t frame, float weight, dim3 grid, size_t lds, float4* out,
+                           DevCounters* dc, hipStream_t stream) {
   if (c->layout == VX_LAYOUT_BRICKF32)
-    hipLaunchKernelGGL((render_generic<MODE, LAYOUT_BF>), grid, dim3(256), lds, c->stream, c->params,
-                       c->dv, c->tf, c->tf_len, c->slab, frame, weight, c->tm, c->dc);
+    hipLaunchKernelGGL((render_generic<MODE, LAYOUT_BF>), grid, dim3(256), lds, stream, c->params,
+                       c->dv, c->tf, c->tf_len, out, frame, weight, c->tm, dc);
   else if (c->layout == VX_LAYOUT_CELLQUAD)
-    hipLaunchKernelGGL((render_generic<MODE, LAYOUT_CQ>), grid, dim3(256), lds, c->stream, c->params,
-                       c->dv, c->tf, c->tf_len, c->slab, frame, weight, c->tm, c->dc);
+    hipLaunchKernelGGL((render_generic<MODE, LAYOUT_CQ>), grid, dim3(256), lds, stream, c->params,
+                       c->dv, c->tf, c->tf_len, out, frame, weight, c->tm, dc);
   else
-    hipLaunchKernelGGL((render_generic<MODE, LAYOUT_REF>), grid, dim3(256), lds, c->stream, c->params,
-                       c->dv, c->tf, c->tf_len, c->slab, frame, weight, c->tm, c->dc);
+    hipLaunchKernelGGL((render_generic<MODE, LAYOUT_REF>), grid, dim3(256), lds, stream, c->params,
+                       c->dv, c->tf, c->tf_len, out, frame, weight, c->tm, dc);
 }
 
 extern "C" {
@@ -359,6 +390,13 @@ void vx_destroy(VxContext* c) {
   if (c->display) (void)hipFree(c->display);
   if (c->dc) (void)hipFree(c->dc);
   if (c->order) (void)hipFree(c->order);
+  for (auto& p : c->pipes) {
+    if (p.stream) { (void)hipStreamSynchronize(p.stream); (void)hipStreamDestroy(p.stream); }
+    if (p.result) (void)hipFree(p.result);
+    if (p.dc) (void)hipFree(p.dc);
+    if (p.done) (void)hipEventDestroy(p.done);
+    if (p.merged) (void)hipEventDestroy(p.merged);
+  }
   if (c->own_stream) (void)hipStreamDestroy(c->own_stream);
   delete c;
 }
@@ -545,8 +583,7 @@ int vx_resize(VxContext* c, uint32_t w, uint32_t h) {
   return alloc_framebuffers(c);
 }
 
-int vx_render_frame(VxContext* c, uint32_t frame_index, float sample_weight) {
-  if (!c) return VX_ERR_INVALID;
+static int prepare_render(VxContext* c, dim3& grid) {
   if (!c->has_volume) VX_FAIL(c, VX_ERR_NO_VOLUME, "vx_render_frame: no volume uploaded");
   if (!c->has_params) VX_FAIL(c, VX_ERR_INVALID, "vx_render_frame: vx_set_params not called");
   if (!c->tf) VX_FAIL(c, VX_ERR_INVALID, "vx_render_frame: no transfer function");
@@ -565,53 +602,195 @@ int vx_render_frame(VxContext* c, uint32_t frame_index, float sample_weight) {
       }
     }
   }
-  EventPair ev;
+  uint32_t groups = (c->tm.tiles_per_shard + 7u) / 8u;
+  grid = dim3(groups * 128u);
+  return ensure_counters(c, (size_t)grid.x * 4u * 8u);  // x8: the depth-parallel DVR grid
+}
+
+static bool is_tuned(const VxContext* c) {
+  return c->params.render_mode == VX_MODE_DVR && c->layout != VX_LAYOUT_REFERENCE && c->dvr_variant != 0 &&
+         !c->params.debug_hits && c->tf_len <= TF_LDS_MAX;
+}
+
+// one render-kernel launch into `out` (accumulator or a pipeline result slab)
+static hipError_t launch_render(VxContext* c, uint32_t frame_index, float weight, dim3 grid, float4* out,
+                                DevCounters* dc, hipStream_t stream) {
+  size_t lds = c->tf_len <= TF_LDS_MAX ? (size_t)c->tf_len * sizeof(float4) : 0;
+  int mode = c->params.render_mode;
+  bool tuned = is_tuned(c);
+  if (tuned && c->layout == VX_LAYOUT_BRICKF32) {
+    launch_dvr_tile(c->params, c->dv, c->tf, c->tf_len, out, frame_index, weight, c->tm, dc, stream);
+  } else if (tuned) {
+    launch_dvr_cq(c->params, c->dv, c->tf, c->tf_len, out, frame_index, weight, c->tm, dc, stream,
+                  (c->use_order && !c->dp_active()) ? c->order : nullptr);
+  } else {
+    switch (mode) {
+      case VX_MODE_DEFAULT: launch_generic<VX_MODE_DEFAULT>(c, frame_index, weight, grid, lds, out, dc, stream); break;
+      case VX_MODE_NO_DDA: launch_generic<VX_MODE_NO_DDA>(c, frame_index, weight, grid, lds, out, dc, stream); break;
+      case VX_MODE_RAYMARCH: launch_generic<VX_MODE_RAYMARCH>(c, frame_index, weight, grid, lds, out, dc, stream); break;
+      case VX_MODE_DVR: launch_generic<VX_MODE_DVR>(c, frame_index, weight, grid, lds, out, dc, stream); break;
+      default: launch_generic<VX_MODE_DVR_PHONG>(c, frame_index, weight, grid, lds, out, dc, stream); break;
+    }
+  }
+  return hipGetLastError();
+}
+
+static int take_events(VxContext* c, EventPair& ev) {
   if (c->free_events.empty()) {
     if (c->pending_events.size() >= 4096) drain_events(c);
     if (c->free_events.empty()) {
       VX_HIP(c, hipEventCreate(&ev.a));
       VX_HIP(c, hipEventCreate(&ev.b));
+      ev.launches = 1;
+      return VX_OK;
     }
   }
-  if (!c->free_events.empty()) {
-    ev = c->free_events.back();
-    c->free_events.pop_back();
-  }
-  uint32_t groups = (c->tm.tiles_per_shard + 7u) / 8u;
-  dim3 grid(groups * 128u);
-  {
-    int rc = ensure_counters(c, (size_t)grid.x * 4u * 8u);  // x8: the depth-parallel DVR grid
-    if (rc) return rc;
-  }
-  size_t lds = c->tf_len <= TF_LDS_MAX ? (size_t)c->tf_len * sizeof(float4) : 0;
+  ev = c->free_events.back();
+  c->free_events.pop_back();
+  ev.launches = 1;
+  return VX_OK;
+}
+
+int vx_render_frame(VxContext* c, uint32_t frame_index, float sample_weight) {
+  if (!c) return VX_ERR_INVALID;
+  dim3 grid;
+  int rc = prepare_render(c, grid);
+  if (rc) return rc;
+  EventPair ev;
+  if ((rc = take_events(c, ev))) return rc;
   VX_HIP(c, hipEventRecord(ev.a, c->stream));
-  int mode = c->params.render_mode;
-  bool tuned = (mode == VX_MODE_DVR && c->layout != VX_LAYOUT_REFERENCE && c->dvr_variant != 0 &&
-                !c->params.debug_hits && c->tf_len <= TF_LDS_MAX);
-  if (tuned && c->layout == VX_LAYOUT_BRICKF32) {
-    launch_dvr_tile(c->params, c->dv, c->tf, c->tf_len, c->slab, frame_index, sample_weight, c->tm,
-                    c->dc, c->stream);
-  } else if (tuned) {
-    launch_dvr_cq(c->params, c->dv, c->tf, c->tf_len, c->slab, frame_index, sample_weight, c->tm,
-                  c->dc, c->stream, (c->use_order && !c->dp_active()) ? c->order : nullptr);
-  } else {
-    switch (mode) {
-      case VX_MODE_DEFAULT: launch_generic<VX_MODE_DEFAULT>(c, frame_index, sample_weight, grid, lds); break;
-      case VX_MODE_NO_DDA: launch_generic<VX_MODE_NO_DDA>(c, frame_index, sample_weight, grid, lds); break;
-      case VX_MODE_RAYMARCH: launch_generic<VX_MODE_RAYMARCH>(c, frame_index, sample_weight, grid, lds); break;
-      case VX_MODE_DVR: launch_generic<VX_MODE_DVR>(c, frame_index, sample_weight, grid, lds); break;
-      default: launch_generic<VX_MODE_DVR_PHONG>(c, frame_index, sample_weight, grid, lds); break;
-    }
-  }
-  hipError_t le = hipGetLastError();
+  hipError_t le = launch_render(c, frame_index, sample_weight, grid, c->slab, c->dc, c->stream);
   VX_HIP(c, hipEventRecord(ev.b, c->stream));
-  if (tuned && c->layout == VX_LAYOUT_CELLQUAD && c->use_order && !c->dp_active() && le == hipSuccess && c->order_builds_left > 0) {
+  const bool ordered = is_tuned(c) && c->layout == VX_LAYOUT_CELLQUAD && c->use_order && !c->dp_active();
+  if (!ordered) c->order_builds_left = 0;
+  if (ordered && le == hipSuccess && c->order_builds_left > 0) {
     c->order_builds_left--;
     hipLaunchKernelGGL(build_order, dim3(1), dim3(1024), 0, c->stream, c->dc, c->order, grid.x);
     le = hipGetLastError();
   }
   c->pending_events.push_back(ev);
   c->launches++;
+  if (le != hipSuccess) VX_FAIL(c, VX_ERR_DEVICE, "render kernel launch: %s", hipGetErrorString(le));
+  return VX_OK;
+}
+
+static int ensure_pipes(VxContext* c, int n) {
+  size_t waves = c->dc_waves;
+  if ((int)c->pipes.size() >= n && c->pipe_quads == c->slab_quads && c->pipe_waves == waves) return VX_OK;
+  VX_HIP(c, hipStreamSynchronize(c->stream));
+  for (auto& p : c->pipes) {
+    if (p.stream) (void)hipStreamSynchronize(p.stream);
+    if (p.result) (void)hipFree(p.result);
+    if (p.dc) {
+      // keep what these records have counted
+      std::vector<DevCounters> h(c->pipe_waves);
+      if (hipMemcpy(h.data(), p.dc, h.size() * sizeof(DevCounters), hipMemcpyDeviceToHost) == hipSuccess)
+        for (const auto& w : h) {
+          c->base.samples += w.samples; c->base.lane_slots += w.slots; c->base.rays += w.rays;
+          c->base.pixels += w.pixels; c->base.skip_steps += w.skips; c->base.grad_samples += w.grads;
+        }
+      (void)hipFree(p.dc);
+    }
+    p.result = nullptr;
+    p.dc = nullptr;
+  }
+  if ((int)c->pipes.size() < n) c->pipes.resize(n);
+  for (auto& p : c->pipes) {
+    if (!p.stream) VX_HIP(c, hipStreamCreateWithFlags(&p.stream, hipStreamNonBlocking));
+    if (!p.done) VX_HIP(c, hipEventCreateWithFlags(&p.done, hipEventDisableTiming));
+    if (!p.merged) VX_HIP(c, hipEventCreateWithFlags(&p.merged, hipEventDisableTiming));
+    p.has_merged = false;
+    VX_HIP(c, hipMalloc(&p.result, c->slab_quads * sizeof(float4)));
+    VX_HIP(c, hipMalloc(&p.dc, waves * sizeof(DevCounters)));
+    VX_HIP(c, hipMemset(p.dc, 0, waves * sizeof(DevCounters)));
+  }
+  c->pipe_quads = c->slab_quads;
+  c->pipe_waves = waves;
+  return VX_OK;
+}
+
+// `count` accumulation frames first_frame.. with their sample weights, up to `in_flight` of them
+// concurrently (frames are independent given their index; only the running mean is ordered, and
+// it is applied afterwards, in order, by merge_results -> bit-identical to count vx_render_frame
+// calls).  Hides the latency-bound tail of one frame behind the bulk of the next ones.
+int vx_render_frames(VxContext* c, uint32_t first_frame, uint32_t count, const float* weights, int in_flight) {
+  if (!c || (!weights && count)) return VX_ERR_INVALID;
+  if (in_flight > MERGE_MAX) in_flight = MERGE_MAX;
+  uint32_t done = 0;
+  // frames that still refresh the launch order, and the degenerate cases, go one by one
+  while (done < count && (in_flight <= 1 || c->order_builds_left > 0 || !c->has_params || c->dc_waves == 0)) {
+    int rc = vx_render_frame(c, first_frame + done, weights[done]);
+    if (rc) return rc;
+    ++done;
+  }
+  if (done == count) return VX_OK;
+  dim3 grid;
+  int rc = prepare_render(c, grid);
+  if (rc) return rc;
+  if ((rc = ensure_pipes(c, in_flight))) return rc;
+  EventPair ev;
+  if ((rc = take_events(c, ev))) return rc;
+  ev.launches = count - done;
+  VX_HIP(c, hipEventRecord(ev.a, c->stream));
+  hipError_t le = hipSuccess;
+  if (is_tuned(c) && c->layout == VX_LAYOUT_CELLQUAD && !c->dp_active()) {
+    // several frames per launch (see MultiOut): one kernel for up to in_flight frames, then the
+    // ordered blend of their results
+    const uint32_t nqm = (uint32_t)c->slab_quads;
+    while (done < count && le == hipSuccess) {
+      uint32_t n = count - done < (uint32_t)in_flight ? count - done : (uint32_t)in_flight;
+      MultiOut mo{};
+      MergeArgs ma{};
+      mo.count = n;
+      ma.count = n;
+      for (uint32_t i = 0; i < n; ++i) {
+        mo.out[i] = c->pipes[i].result;
+        mo.dc[i] = c->pipes[i].dc;
+        mo.frame[i] = first_frame + done + i;
+        ma.result[i] = c->pipes[i].result;
+        ma.weight[i] = weights[done + i];
+      }
+      launch_dvr_cq_multi(c->params, c->dv, c->tf, c->tf_len, mo, 0.0f, c->tm, c->stream,
+                          c->use_order ? c->order : nullptr);
+      le = hipGetLastError();
+      if (le == hipSuccess) {
+        hipLaunchKernelGGL(merge_results, dim3((nqm + 255) / 256), dim3(256), 0, c->stream, c->slab, ma, nqm);
+        le = hipGetLastError();
+      }
+      done += n;
+      c->launches += n;
+    }
+    VX_HIP(c, hipEventRecord(ev.b, c->stream));
+    c->pending_events.push_back(ev);
+    if (le != hipSuccess) VX_FAIL(c, VX_ERR_DEVICE, "render kernel launch: %s", hipGetErrorString(le));
+    return VX_OK;
+  }
+  // other kernels: rolling window of frames on separate streams
+  // rolling window: frame f renders on slot f % in_flight as soon as that slot's previous result has
+  // been blended; the blends happen on the main stream, in frame order
+  const uint32_t P = (uint32_t)in_flight;
+  const uint32_t nq = (uint32_t)c->slab_quads;
+  for (; done < count && le == hipSuccess; ++done) {
+    auto& p = c->pipes[c->pipe_next % P];
+    c->pipe_next = (c->pipe_next + 1) % P;
+    if (p.has_merged) VX_HIP(c, hipStreamWaitEvent(p.stream, p.merged, 0));
+    le = launch_render(c, first_frame + done, 0.0f, grid, p.result, p.dc, p.stream);  // weight 0: raw result
+    VX_HIP(c, hipEventRecord(p.done, p.stream));
+    VX_HIP(c, hipStreamWaitEvent(c->stream, p.done, 0));
+    if (le == hipSuccess) {
+      MergeArgs ma{};
+      ma.count = 1;
+      ma.result[0] = p.result;
+      ma.weight[0] = weights[done];
+      hipLaunchKernelGGL(merge_results, dim3((nq + 255) / 256), dim3(256), 0, c->stream, c->slab, ma, nq);
+      le = hipGetLastError();
+    }
+    VX_HIP(c, hipEventRecord(p.merged, c->stream));
+    p.has_merged = true;
+    c->launches++;
+  }
+  VX_HIP(c, hipEventRecord(ev.b, c->stream));
+  c->pending_events.push_back(ev);
   if (le != hipSuccess) VX_FAIL(c, VX_ERR_DEVICE, "render kernel launch: %s", hipGetErrorString(le));
   return VX_OK;
 }
@@ -704,7 +883,10 @@ int vx_reset_counters(VxContext* c) {
   if (!c) return VX_ERR_INVALID;
   VX_HIP(c, hipStreamSynchronize(c->stream));
   drain_events(c);
-  if (c->dc) VX_HIP(c, hipMemset(c->dc, 0, c->dc_waves * sizeof(DevCounters)));
+  {
+    int rc = fold_counters(c);   // zeroes every record array (accumulator and pipeline slots)
+    if (rc) return rc;
+  }
   c->base = VxCounters{};
   c->kernel_ms = c->last_kernel_ms = 0.0;
   c->launches = 0;

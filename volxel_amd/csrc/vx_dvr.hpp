@@ -64,6 +64,16 @@ VXD void dvr_store(const VxParams& p, const DvrRay& r, float Cx, float Cy, float
   slab[si] = o;
 }
 
+// Several independent accumulation frames in ONE launch: launch slot s renders frame slot s % count
+// of logical block order[s / count], so the longest blocks of all frames start first and the
+// latency-bound tail is paid once per `count` frames.  count == 1 is the plain per-frame launch.
+struct MultiOut {
+  float4* out[8];
+  DevCounters* dc[8];
+  uint32_t frame[8];
+  uint32_t count;
+};
+
 // U = march steps per loop iteration: the 2*U gathers of a batch are issued back to back before
 // any of them is consumed, so a wave keeps 2*U loads in flight instead of 2 (the march is
 // latency-bound on the longest rays: tools/tail_probe.py).
@@ -75,9 +85,8 @@ VXD void dvr_store(const VxParams& p, const DvrRay& r, float Cx, float Cy, float
 template <int U, bool SKIP>
 __global__ __launch_bounds__(256) void render_dvr_cq(const VxParams p, const DevVolume v,
                                                       const float4* __restrict__ tf_global,
-                                                      uint32_t tf_len, float4* __restrict__ slab,
-                                                      uint32_t frame, float weight, const TileMap tm,
-                                                      DevCounters* __restrict__ dc,
+                                                      uint32_t tf_len, const MultiOut mo, float weight,
+                                                      const TileMap tm,
                                                       const uint32_t* __restrict__ order) {
   extern __shared__ float4 tf_lds[];
   uint32_t* mask_lds = reinterpret_cast<uint32_t*>(tf_lds + tf_len);
@@ -85,8 +94,15 @@ __global__ __launch_bounds__(256) void render_dvr_cq(const VxParams p, const Dev
   if (SKIP)
     for (uint32_t i = threadIdx.x; i < v.skip_words; i += blockDim.x) mask_lds[i] = v.skip_bits[i];
   __syncthreads();
-  // launch slot -> logical block (longest-first order of the previous frame, same XCD class)
-  const uint32_t blk = order ? order[blockIdx.x] : blockIdx.x;
+  // launch slot -> (frame slot, logical block); blocks in longest-first order of the previous frame
+  // launch index = bslot*count + fslot.  (An XCD-class-preserving interleave was measured slower
+  // at 2 and 4 shards: one frame slot per XCD class balances better than one tile set per class.)
+  const uint32_t fslot = mo.count > 1 ? blockIdx.x % mo.count : 0u;
+  const uint32_t bslot = mo.count > 1 ? blockIdx.x / mo.count : blockIdx.x;
+  const uint32_t blk = order ? order[bslot] : bslot;
+  float4* __restrict__ slab = mo.out[fslot];
+  DevCounters* __restrict__ dc = mo.dc[fslot];
+  const uint32_t frame = mo.frame[fslot];
   uint32_t lt, sub;
   if (!block_to_tile(blk, tm, lt, sub)) return;
   const uint32_t wt = sub * 4u + (threadIdx.x >> 6), lane = threadIdx.x & 63u;
@@ -434,9 +450,27 @@ __global__ __launch_bounds__(256) void render_dvr_dp(const VxParams p, const Dev
   add_counts(dc, n_samples, n_rays, n_px, n_skipped, 0u, n_slots);
 }
 
+inline void launch_dvr_cq_multi(const VxParams& p, const DevVolume& v, const float4* tf, uint32_t tf_len,
+                                const MultiOut& mo, float weight, const TileMap& tm, hipStream_t stream,
+                                const uint32_t* order);
+
 inline void launch_dvr_cq(const VxParams& p, const DevVolume& v, const float4* tf, uint32_t tf_len,
                           float4* slab, uint32_t frame, float weight, const TileMap& tm,
                           DevCounters* dc, hipStream_t stream, const uint32_t* order) {
+  MultiOut mo{};
+  mo.count = 1;
+  mo.out[0] = slab;
+  mo.dc[0] = dc;
+  mo.frame[0] = frame;
+  launch_dvr_cq_multi(p, v, tf, tf_len, mo, weight, tm, stream, order);
+}
+
+inline void launch_dvr_cq_multi(const VxParams& p, const DevVolume& v, const float4* tf, uint32_t tf_len,
+                                const MultiOut& mo, float weight, const TileMap& tm, hipStream_t stream,
+                                const uint32_t* order) {
+  float4* slab = mo.out[0];
+  DevCounters* dc = mo.dc[0];
+  const uint32_t frame = mo.frame[0];
   uint32_t groups = (tm.tiles_per_shard + 7u) / 8u;
   static const int dp = [] { const char* e = getenv("VX_DVR_DP"); return e ? atoi(e) : -1; }();
   // depth-parallel waves only on request (VX_DVR_DP=1): they cut the longest dependent chain 8x
@@ -453,11 +487,11 @@ inline void launch_dvr_cq(const VxParams& p, const DevVolume& v, const float4* t
     return;
   }
   static const int unroll = [] { const char* e = getenv("VX_DVR_UNROLL"); return e ? atoi(e) : 4; }();
-  dim3 grid(groups * 128u), block(256);
+  dim3 grid(groups * 128u * mo.count), block(256);
   const bool skip = p.dvr_skip_empty && v.skip_bits;
   size_t lds = (size_t)tf_len * sizeof(float4) + (skip ? (size_t)v.skip_words * 4u : 0u);
 #define VX_LAUNCH(UU, SS) \
-  hipLaunchKernelGGL((render_dvr_cq<UU, SS>), grid, block, lds, stream, p, v, tf, tf_len, slab, frame, weight, tm, dc, order)
+  hipLaunchKernelGGL((render_dvr_cq<UU, SS>), grid, block, lds, stream, p, v, tf, tf_len, mo, weight, tm, order)
   if (skip) {
     switch (unroll) {
       case 1: VX_LAUNCH(1, true); break;

@@ -196,6 +196,29 @@ __global__ __launch_bounds__(256) void build_brickf32(const DevVolume v, float* 
                                 (int)(bz * 8u + (l >> 6)));
 }
 
+// ---- ordered running-mean blend of pipelined frame results (fragment.frag:158 applied n times) ----
+constexpr int MERGE_MAX = 8;
+struct MergeArgs {
+  const float4* result[MERGE_MAX];
+  float weight[MERGE_MAX];
+  uint32_t count;
+};
+__global__ __launch_bounds__(256) void merge_results(float4* __restrict__ slab, const MergeArgs a, uint32_t n) {
+  uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  float4 acc = slab[i];
+  for (uint32_t k = 0; k < a.count; ++k) {
+    float w = a.weight[k];
+    float4 r = a.result[k][i];
+    float px = w != 0.0f ? acc.x : 0.0f, py = w != 0.0f ? acc.y : 0.0f, pz = w != 0.0f ? acc.z : 0.0f;
+    acc.x = fma_(1.0f - w, r.x, w * px);
+    acc.y = fma_(1.0f - w, r.y, w * py);
+    acc.z = fma_(1.0f - w, r.z, w * pz);
+    acc.w = 1.0f;
+  }
+  slab[i] = acc;
+}
+
 // ---- slab(s) -> row-major image --------------------------------------------------------
 // gathered = shard_count slabs back to back (each tiles_per_shard*4096 float4)
 __global__ __launch_bounds__(256) void detile(const float4* __restrict__ gathered,

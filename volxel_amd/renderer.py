@@ -247,11 +247,20 @@ class Volxel3DRenderer:
         return p
 
     # -- viewer.ts:1183-1293 ------------------------------------------------------------
-    def render(self, frames: int = 1, rebind: bool = True):
+    def render(self, frames: int = 1, rebind: bool = True, in_flight: int = 1):
         """Render `frames` accumulation samples (the body of render() while
-        frameIndex <= maxSamples).  Asynchronous; call finish() or a read_* to wait."""
+        frameIndex <= maxSamples).  Asynchronous; call finish() or a read_* to wait.
+        in_flight > 1 renders that many frames concurrently (vx_render_frames): same bits."""
         if rebind:
             self.bind_uniforms()
+        if in_flight > 1 and frames > 1:
+            n = max(0, min(frames, self.settings.max_samples + 1 - self.frame_index))
+            if n:
+                w = (C.c_float * n)(*[sample_weight(self.frame_index + i, self.low_resolution_duration)
+                                      for i in range(n)])
+                self._check(self._lib.vx_render_frames(self._ctx, self.frame_index, n, w, int(in_flight)))
+                self.frame_index += n
+            return
         for _ in range(frames):
             if self.frame_index > self.settings.max_samples:     # viewer.ts:1194
                 break
