@@ -129,7 +129,8 @@ typedef struct VxCounters {
   uint64_t grad_samples; /* samples that also evaluated the 6-tap gradient (DVR_PHONG)    */
   uint64_t lane_slots;   /* 64 x wave iterations of the DVR march loop (samples / lane_slots
                             = SIMD lane utilisation); 0 for kernels that do not count it   */
-  uint64_t launches;     /* render-kernel launches                                        */
+  uint64_t launches;     /* render-kernel launches (one launch may cover several frames)   */
+  uint64_t frames;       /* accumulation frames rendered                                  */
   double kernel_ms;      /* sum of HIP-event durations of those launches                  */
   double last_kernel_ms; /* duration of the most recent launch                            */
 } VxCounters;

@@ -17,8 +17,8 @@ for n in (1, 2, 4, 8):
         r.render(frames=4, rebind=False); r.finish(); r.reset_counters()
         r.render(frames=32, rebind=False, in_flight=in_flight); r.finish()
         c = r.counters()
-        ms = c.kernel_ms / c.launches
-        worst = max(worst, ms); tot = c.samples / c.launches
+        ms = c.kernel_ms / c.frames
+        worst = max(worst, ms); tot = c.samples / c.frames
         r.close()
     if base is None: base = worst
     print(json.dumps(dict(skip=skip, in_flight=in_flight, shards=n, worst_rank_ms=round(worst, 4), predicted_speedup=round(base / worst, 2),

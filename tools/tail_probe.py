@@ -17,6 +17,6 @@ for ms in (25, 50, 100, 200, 400, 800, 1600, 1 << 20):
     r.render(frames=3, rebind=False); r.finish(); r.reset_counters()
     r.render(frames=10, rebind=False); r.finish()
     c = r.counters()
-    ms_frame = c.kernel_ms / c.launches
-    print(json.dumps(dict(layout=layout, skip=skip, max_steps=ms, ms=round(ms_frame, 4), Msamples=round(c.samples / c.launches / 1e6, 2),
+    ms_frame = c.kernel_ms / c.frames
+    print(json.dumps(dict(layout=layout, skip=skip, max_steps=ms, ms=round(ms_frame, 4), Msamples=round(c.samples / c.frames / 1e6, 2),
                           gsps=round(c.samples / c.kernel_ms / 1e6, 1), util=round(c.samples / max(c.lane_slots, 1), 3))))

@@ -71,7 +71,7 @@ struct VxContext {
   VxCounters base{};           // totals folded in when the record array is reallocated
   std::vector<EventPair> free_events, pending_events;
   double kernel_ms = 0.0, last_kernel_ms = 0.0;
-  uint64_t launches = 0;
+  uint64_t launches = 0, frames = 0;
   int dvr_variant = -1;  // -1: tuned kernel; 0: generic
 
   // frame pipelining (vx_render_frames): independent accumulation frames in flight on their own
@@ -670,6 +670,7 @@ int vx_render_frame(VxContext* c, uint32_t frame_index, float sample_weight) {
   }
   c->pending_events.push_back(ev);
   c->launches++;
+  c->frames++;
   if (le != hipSuccess) VX_FAIL(c, VX_ERR_DEVICE, "render kernel launch: %s", hipGetErrorString(le));
   return VX_OK;
 }
@@ -731,12 +732,12 @@ int vx_render_frames(VxContext* c, uint32_t first_frame, uint32_t count, const f
   EventPair ev;
   if ((rc = take_events(c, ev))) return rc;
   ev.launches = count - done;
-  VX_HIP(c, hipEventRecord(ev.a, c->stream));
   hipError_t le = hipSuccess;
   if (is_tuned(c) && c->layout == VX_LAYOUT_CELLQUAD && !c->dp_active()) {
     // several frames per launch (see MultiOut): one kernel for up to in_flight frames, then the
     // ordered blend of their results
     const uint32_t nqm = (uint32_t)c->slab_quads;
+    c->free_events.push_back(ev);   // per-launch intervals instead of one batch interval
     while (done < count && le == hipSuccess) {
       uint32_t n = count - done < (uint32_t)in_flight ? count - done : (uint32_t)in_flight;
       MultiOut mo{};
@@ -750,22 +751,27 @@ int vx_render_frames(VxContext* c, uint32_t first_frame, uint32_t count, const f
         ma.result[i] = c->pipes[i].result;
         ma.weight[i] = weights[done + i];
       }
+      EventPair e2;
+      if ((rc = take_events(c, e2))) return rc;
+      VX_HIP(c, hipEventRecord(e2.a, c->stream));
       launch_dvr_cq_multi(c->params, c->dv, c->tf, c->tf_len, mo, 0.0f, c->tm, c->stream,
                           c->use_order ? c->order : nullptr);
       le = hipGetLastError();
+      VX_HIP(c, hipEventRecord(e2.b, c->stream));   // the render kernel alone; the blend is outside
+      c->pending_events.push_back(e2);
       if (le == hipSuccess) {
         hipLaunchKernelGGL(merge_results, dim3((nqm + 255) / 256), dim3(256), 0, c->stream, c->slab, ma, nqm);
         le = hipGetLastError();
       }
       done += n;
-      c->launches += n;
+      c->launches += 1;
+      c->frames += n;
     }
-    VX_HIP(c, hipEventRecord(ev.b, c->stream));
-    c->pending_events.push_back(ev);
     if (le != hipSuccess) VX_FAIL(c, VX_ERR_DEVICE, "render kernel launch: %s", hipGetErrorString(le));
     return VX_OK;
   }
   // other kernels: rolling window of frames on separate streams
+  VX_HIP(c, hipEventRecord(ev.a, c->stream));
   // rolling window: frame f renders on slot f % in_flight as soon as that slot's previous result has
   // been blended; the blends happen on the main stream, in frame order
   const uint32_t P = (uint32_t)in_flight;
@@ -788,6 +794,7 @@ int vx_render_frames(VxContext* c, uint32_t first_frame, uint32_t count, const f
     VX_HIP(c, hipEventRecord(p.merged, c->stream));
     p.has_merged = true;
     c->launches++;
+    c->frames++;
   }
   VX_HIP(c, hipEventRecord(ev.b, c->stream));
   c->pending_events.push_back(ev);
@@ -874,6 +881,7 @@ int vx_get_counters(VxContext* c, VxCounters* out) {
   out->grad_samples = c->base.grad_samples;
   out->lane_slots = c->base.lane_slots;
   out->launches = c->launches;
+  out->frames = c->frames;
   out->kernel_ms = c->kernel_ms;
   out->last_kernel_ms = c->last_kernel_ms;
   return VX_OK;
@@ -890,6 +898,7 @@ int vx_reset_counters(VxContext* c) {
   c->base = VxCounters{};
   c->kernel_ms = c->last_kernel_ms = 0.0;
   c->launches = 0;
+  c->frames = 0;
   return VX_OK;
 }
 

@@ -258,7 +258,7 @@ static napi_value n_get_counters(napi_env env, napi_callback_info info) {
   NAPI_OK(napi_create_double(env, (double)(val), &v));      \
   NAPI_OK(napi_set_named_property(env, o, name, v));
   PUT("samples", k.samples) PUT("rays", k.rays) PUT("pixels", k.pixels) PUT("skipSteps", k.skip_steps)
-  PUT("gradSamples", k.grad_samples) PUT("laneSlots", k.lane_slots) PUT("launches", k.launches)
+  PUT("gradSamples", k.grad_samples) PUT("laneSlots", k.lane_slots) PUT("launches", k.launches) PUT("frames", k.frames)
   PUT("kernelMs", k.kernel_ms) PUT("lastKernelMs", k.last_kernel_ms)
 #undef PUT
   return o;
