@@ -36,6 +36,14 @@ typedef struct VxBrickGrid VxBrickGrid;
  */
 int vxb_build_from_u16(const uint16_t* voxels, const uint32_t dims[3], const float spacing[3],
                        uint16_t max_value, int n_threads, VxBrickGrid** out);
+/*
+ * read_dicoms_to_grid (lib.rs:193-202): n_files Part-10 DICOM buffers (uncompressed, 16-bit unsigned
+ * monochrome, implicit or explicit VR little endian), stacked in the order given
+ * (lib.rs:142-191), then BrickGrid::construct.  Errors carry the reference's panic messages
+ * ("Currently only 16bit samples are supported", ...).
+ */
+int vxb_read_dicoms_to_grid(const uint8_t* const* files, const uint64_t* sizes, uint32_t n_files,
+                            int n_threads, VxBrickGrid** out);
 void vxb_free(VxBrickGrid* g);
 const char* vxb_last_error(void);
 

@@ -41,12 +41,32 @@ def _check_grid(oracle, tmp_path):
     return g
 
 
+def _write_dicoms(tmp_path):
+    from tests.dicom_writer import write_slice
+    from volxel_amd import synth
+    vox, _ = synth.sphere(32)
+    os.makedirs(tmp_path / "dicom")
+    for z in range(vox.shape[0]):
+        with open(tmp_path / "dicom" / ("%04d.dcm" % z), "wb") as f:
+            f.write(write_slice(vox[z], spacing=(1.0, 1.0), thickness=2.0, syntax=("1.2.840.10008.1.2", "1.2.840.10008.1.2.1")[z & 1]))
+
+
+def _check_dicom_path(tmp_path):
+    assert np.array_equal(np.fromfile(tmp_path / "atlas_dcm.bin", dtype=np.uint8),
+                          np.fromfile(tmp_path / "atlas.bin", dtype=np.uint8))
+    m = json.load(open(tmp_path / "meta_dcm.json"))
+    assert m["histogramLength"] == 4096 and m["transform"][0] == 1.0 and m["transform"][10] == 2.0
+    assert "DICM" in json.load(open(tmp_path / "dcm_error.json"))["msg"]
+
+
 def test_node_host_cpu(oracle, tmp_path):
     import torch
     if torch.cuda.is_available():
         pytest.skip("GPU present: covered by the gpu test")
+    _write_dicoms(tmp_path)
     _run(tmp_path)
     _check_grid(oracle, tmp_path)
+    _check_dicom_path(tmp_path)
     assert json.load(open(tmp_path / "nogpu.json"))["threw"] is True   # no JavaScript/CPU fallback
     keys = subprocess.check_output(["node", "-e", "console.log(Object.keys(require('%s')).join(','))" % NAPI]).decode()
     for k in ("Volxel3DDicomRenderer", "VolxelRenderMode", "generateTransferFunction"):

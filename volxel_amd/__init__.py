@@ -8,4 +8,4 @@ from .transfer import (default_transfer_function, generate_transfer_function,  #
                        parse_transfer_function)
 from .settings import ViewerSettings, BENCHMARK_SETTINGS, verify_settings, load_settings  # noqa: F401
 from .scene import Camera, Volume, Grid  # noqa: F401
-from .preprocessor import read_u16_stack_to_grid, BrickGridMessage  # noqa: F401
+from .preprocessor import read_u16_stack_to_grid, read_dicoms_to_grid, BrickGridMessage  # noqa: F401

@@ -115,6 +115,7 @@ def load_library():
         "vx_debug_build_skip_mask": ([vp, P(u32), vp, u32, P(VxParams), vp, P(u32), P(u32)], i32),
         # preprocessor
         "vxb_build_from_u16": ([vp, P(u32), P(C.c_float), C.c_uint16, i32, P(vp)], i32),
+        "vxb_read_dicoms_to_grid": ([P(vp), P(u64), u32, i32, P(vp)], i32),
         "vxb_free": ([vp], None),
         "vxb_last_error": ([], C.c_char_p),
         "vxb_indirection_size": ([vp, P(u32)], None),

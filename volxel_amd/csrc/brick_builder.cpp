@@ -114,8 +114,11 @@ extern "C" {
 
 const char* vxb_last_error(void) { return g_err.c_str(); }
 
-int vxb_build_from_u16(const uint16_t* vox, const uint32_t dims[3], const float spacing[3],
-                       uint16_t max_value, int n_threads, VxBrickGrid** out) {
+}  // extern "C"
+
+// shared by vxb_build_from_u16 and the DICOM reader; hist_bins == 0: 4096 / 65536 by max value
+int vxb_build_internal(const uint16_t* vox, const uint32_t dims[3], const float spacing[3], uint16_t max_value,
+                       uint32_t hist_bins, int n_threads, VxBrickGrid** out) {
   if (!vox || !dims || !spacing || !out || !dims[0] || !dims[1] || !dims[2]) {
     g_err = "vxb_build_from_u16: null or empty input";
     return VXB_ERR_INVALID;
@@ -157,7 +160,9 @@ int vxb_build_from_u16(const uint16_t* vox, const uint32_t dims[3], const float 
     return VXB_ERR_INVALID;
   }
   g->max_value = max_value;
-  const uint32_t bins = max_value < 4096 ? 4096u : 65536u;
+  const uint32_t bins = hist_bins ? hist_bins : (max_value < 4096 ? 4096u : 65536u);
+  // explicit hist_bins (DICOM reader): the per-file range check already ran there, and counts of a
+  // later file beyond the first file's bins are dropped by the summation at lib.rs:159-161
   g->histogram.assign(hist.begin(), hist.begin() + bins);
   {  // dicom.rs:39-66
     std::vector<int32_t> grad(bins);
@@ -299,6 +304,15 @@ int vxb_build_from_u16(const uint16_t* vox, const uint32_t dims[3], const float 
   *out = g;
   return VXB_OK;
 }
+
+extern "C" {
+
+int vxb_build_from_u16(const uint16_t* vox, const uint32_t dims[3], const float spacing[3],
+                       uint16_t max_value, int n_threads, VxBrickGrid** out) {
+  return vxb_build_internal(vox, dims, spacing, max_value, 0, n_threads, out);
+}
+
+void vxb_set_error(const char* msg) { g_err = msg ? msg : ""; }
 
 void vxb_free(VxBrickGrid* g) { delete g; }
 

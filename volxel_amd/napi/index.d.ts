@@ -15,6 +15,8 @@ export declare class Volxel3DDicomRenderer {
   constructor(opts?: { width?: number; height?: number; device?: number; layout?: number });
   settings: Record<string, any>; camera: Camera; envStrength: number; frameIndex: number;
   renderMode: keyof typeof VolxelRenderMode;
+  /** restartFromFiles (viewer.ts:833-866) for slices already read into memory */
+  restartFromBytes(files: Uint8Array[], threads?: number): void;
   restartFromVoxels(voxels: Uint16Array, dims: [number, number, number], spacing?: [number, number, number], maxValue?: number, threads?: number): void;
   setupFromGrid(grid: BrickGridMessage): void;
   changeTransferFunc(data: Float32Array, length: number): void;

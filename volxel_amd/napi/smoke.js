@@ -17,6 +17,17 @@ fs.writeFileSync(path.join(out, 'indirection.bin'), Buffer.from(grid.indirection
 fs.writeFileSync(path.join(out, 'range.bin'), Buffer.from(grid.range.buffer));
 fs.writeFileSync(path.join(out, 'meta.json'), JSON.stringify({ atlasSize: grid.atlasSize, indexExtent: grid.indexExtent,
   brickCounter: grid.brickCounter, minMaj: grid.minMaj, mips: grid.rangeMipmaps.map(m => m.stride) }));
+const dcmDir = path.join(out, 'dicom');
+if (fs.existsSync(dcmDir)) {  // worker.ts:101-104 path: DICOM bytes in, brick grid out
+  const files = fs.readdirSync(dcmDir).sort().map(f => new Uint8Array(fs.readFileSync(path.join(dcmDir, f))));
+  const g2 = native.readDicomsToGrid(files, 2);
+  fs.writeFileSync(path.join(out, 'atlas_dcm.bin'), Buffer.from(g2.atlas.buffer));
+  fs.writeFileSync(path.join(out, 'meta_dcm.json'), JSON.stringify({ transform: Array.from(g2.transform),
+    histogramLength: g2.histogram.length, indexExtent: g2.indexExtent }));
+  let msg = '';
+  try { native.readDicomsToGrid([new Uint8Array(200)], 1); } catch (e) { msg = e.message; }
+  fs.writeFileSync(path.join(out, 'dcm_error.json'), JSON.stringify({ msg }));
+}
 const tf = generateTransferFunction([{ color: [1, 1, 1, 0], stop: 0 }, { color: [1, 1, 1, 1], stop: 1 }]);
 fs.writeFileSync(path.join(out, 'tf.bin'), Buffer.from(tf.data.buffer));
 if (process.argv[3] === 'gpu') {

@@ -155,7 +155,12 @@ class Volxel3DDicomRenderer {
     this.settings.renderMode = to; this.restartRendering();
   }
 
-  /** replaces restartFromFiles/Zip/URLs for an already decoded u16 stack (DICOM I/O is row N1) */
+  /** restartFromFiles (viewer.ts:833-866) once the File objects are read: one Uint8Array per slice */
+  restartFromBytes(files, threads = 0) {
+    this.setupFromGrid(native.readDicomsToGrid(files, threads));
+  }
+
+  /** the same for an already decoded u16 stack */
   restartFromVoxels(voxels, dims, spacing = [1, 1, 1], maxValue = 0, threads = 0) {
     this.setupFromGrid(native.buildBrickGrid(voxels, dims, spacing, maxValue, threads));
   }

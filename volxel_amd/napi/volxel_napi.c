@@ -300,6 +300,42 @@ static napi_value make_u32x3(napi_env env, const uint32_t s[3]) {
   return arr;
 }
 
+static napi_value grid_to_object(napi_env env, VxBrickGrid* g);
+
+/* readDicomsToGrid(Array<Uint8Array> files, threads): the wasm export of lib.rs:193-202 as called
+ * at worker.ts:101-104 */
+static napi_value n_read_dicoms_to_grid(napi_env env, napi_callback_info info) {
+  napi_value a[2];
+  if (!get_args(env, info, 2, a)) return NULL;
+  uint32_t n = 0;
+  int32_t threads;
+  bool is_arr = false;
+  NAPI_OK(napi_is_array(env, a[0], &is_arr));
+  if (!is_arr) return throw_msg(env, "readDicomsToGrid: expected an array of Uint8Array");
+  NAPI_OK(napi_get_array_length(env, a[0], &n));
+  NAPI_OK(napi_get_value_int32(env, a[1], &threads));
+  const uint8_t** ptrs = (const uint8_t**)calloc(n ? n : 1, sizeof(*ptrs));
+  uint64_t* sizes = (uint64_t*)calloc(n ? n : 1, sizeof(*sizes));
+  for (uint32_t i = 0; i < n; ++i) {
+    napi_value e;
+    void* p;
+    size_t len;
+    if (napi_get_element(env, a[0], i, &e) != napi_ok || !typed(env, e, napi_uint8_array, &p, &len)) {
+      free(ptrs);
+      free(sizes);
+      return NULL;
+    }
+    ptrs[i] = (const uint8_t*)p;
+    sizes[i] = len;
+  }
+  VxBrickGrid* g = NULL;
+  int rc = vxb_read_dicoms_to_grid(ptrs, sizes, n, threads, &g);
+  free(ptrs);
+  free(sizes);
+  if (rc != VXB_OK) return throw_msg(env, vxb_last_error());
+  return grid_to_object(env, g);
+}
+
 static napi_value n_build_brick_grid(napi_env env, napi_callback_info info) {
   napi_value a[5];
   if (!get_args(env, info, 5, a)) return NULL;
@@ -322,6 +358,10 @@ static napi_value n_build_brick_grid(napi_env env, napi_callback_info info) {
   VxBrickGrid* g = NULL;
   if (vxb_build_from_u16((const uint16_t*)vox, dims, sp, (uint16_t)maxv, threads, &g) != VXB_OK)
     return throw_msg(env, vxb_last_error());
+  return grid_to_object(env, g);
+}
+
+static napi_value grid_to_object(napi_env env, VxBrickGrid* g) {
   uint32_t is[3], rs[3], as[3], ext[3];
   vxb_indirection_size(g, is);
   vxb_range_size(g, rs);
@@ -386,7 +426,8 @@ static napi_value init(napi_env env, napi_value exports) {
       {"uploadTransfer", n_upload_transfer}, {"setParams", n_set_params}, {"sizeofParams", n_sizeof_params},
       {"resize", n_resize}, {"setLayout", n_set_layout}, {"renderFrame", n_render_frame}, {"finish", n_finish},
       {"readAccum", n_read_accum}, {"readDisplay", n_read_display}, {"getCounters", n_get_counters},
-      {"resetCounters", n_reset_counters}, {"version", n_version}, {"buildBrickGrid", n_build_brick_grid}};
+      {"resetCounters", n_reset_counters}, {"version", n_version}, {"buildBrickGrid", n_build_brick_grid},
+      {"readDicomsToGrid", n_read_dicoms_to_grid}};
   for (size_t i = 0; i < sizeof fns / sizeof fns[0]; ++i) {
     napi_value f;
     if (napi_create_function(env, fns[i].name, NAPI_AUTO_LENGTH, fns[i].fn, NULL, &f) != napi_ok ||

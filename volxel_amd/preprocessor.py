@@ -45,6 +45,21 @@ def _view(ptr, n, dtype):
     return np.frombuffer(buf, dtype=dtype).copy()
 
 
+def read_dicoms_to_grid(files, n_threads: int = 0) -> BrickGridMessage:
+    """read_dicoms_to_grid (lib.rs:193-202): `files` = list of bytes objects, one DICOM slice (or
+    multi-frame file) each, in stacking order -- the LOAD_FROM_BYTES message of worker.ts:101-104."""
+    lib = _abi.load_library()
+    bufs = [np.frombuffer(bytes(f), dtype=np.uint8) for f in files]
+    n = len(bufs)
+    ptrs = (C.c_void_p * max(n, 1))(*[b.ctypes.data for b in bufs])
+    sizes = (C.c_uint64 * max(n, 1))(*[b.size for b in bufs])
+    g = C.c_void_p()
+    rc = lib.vxb_read_dicoms_to_grid(ptrs, sizes, n, int(n_threads), C.byref(g))
+    if rc != 0:
+        raise RuntimeError(lib.vxb_last_error().decode())
+    return _message_from_grid(lib, g)
+
+
 def read_u16_stack_to_grid(voxels: np.ndarray, spacing=(1.0, 1.0, 1.0), max_value: int = 0,
                            n_threads: int = 0) -> BrickGridMessage:
     """read_dicoms_to_grid (lib.rs:193-202) for an already decoded u16 stack [z,y,x]."""
@@ -58,6 +73,10 @@ def read_u16_stack_to_grid(voxels: np.ndarray, spacing=(1.0, 1.0, 1.0), max_valu
     rc = lib.vxb_build_from_u16(v.ctypes.data, dims, sp, int(max_value), int(n_threads), C.byref(g))
     if rc != 0:
         raise RuntimeError(lib.vxb_last_error().decode())
+    return _message_from_grid(lib, g)
+
+
+def _message_from_grid(lib, g) -> BrickGridMessage:
     try:
         ind_size = _arr3(lib.vxb_indirection_size, g)
         range_size = _arr3(lib.vxb_range_size, g)
