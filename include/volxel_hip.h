@@ -192,6 +192,9 @@ int vx_render_frame(VxContext* ctx, uint32_t frame_index, float sample_weight);
  * vx_render_frame.  [build] no reference counterpart: WebGL2 draws are serialised. */
 int vx_render_frames(VxContext* ctx, uint32_t first_frame, uint32_t count, const float* weights, int in_flight);
 
+/* current framebuffer size (what vx_read_accum / vx_read_display will write) */
+int vx_render_size(VxContext* ctx, uint32_t* width, uint32_t* height);
+
 /* ---- synchronise: replaces gl.finish() (viewer.ts:1214,1289) */
 int vx_finish(VxContext* ctx);
 
@@ -201,6 +204,12 @@ int vx_read_accum(VxContext* ctx, float* rgba_out);
 /* ---- display pass: replaces the blit program (blit.frag:17-35, viewer.ts:1259-1265):
  *      Hable tonemap + gamma, RGBA8, width*height*4 bytes.  Synchronises. */
 int vx_read_display(VxContext* ctx, uint8_t* rgba8_out, float exposure, float gamma);
+/* ---- the same pass drawn to a canvas of another size, as the viewer does while the low-resolution
+ *      preview (resolutionFactor 0.33, viewer.ts:1167-1188) is up: the blit samples u_result with
+ *      NEAREST filtering (viewer.ts:310-311), i.e. canvas pixel (x,y) shows render pixel
+ *      (floor((x+0.5)*w/out_w), floor((y+0.5)*h/out_h)).  out_w*out_h*4 bytes.  Synchronises. */
+int vx_read_display_scaled(VxContext* ctx, uint8_t* rgba8_out, uint32_t out_w, uint32_t out_h,
+                           float exposure, float gamma);
 
 /* device-side views for a zero-copy host (torch / RCCL gather): the tile-major slab this
  * shard owns (floats = vx_slab_floats) and a de-tiling pass from a gathered set of slabs. */

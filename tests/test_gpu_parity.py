@@ -12,6 +12,8 @@ import ctypes as C
 import os
 
 import numpy as np
+import math
+
 import pytest
 
 pytestmark = pytest.mark.gpu
@@ -234,6 +236,94 @@ def test_display_pass_matches_blit(oracle):
     disp = r.read_display()
     want8, _ = oracle.blit(img, 5.5, 2.2)
     assert np.abs(disp.astype(int) - want8.astype(int)).max() <= 1
+
+
+def test_low_resolution_preview_ramp(oracle):
+    """viewer.ts:925-949,1167-1188: 0.33 x canvas for the first 5 frames after a restart, NEAREST
+    blit to the canvas, then full size and the running mean starts over (viewer.ts:1356)"""
+    from tests.common import benchmark_tf, BENCH_CAM
+    from volxel_amd import Volxel3DRenderer, compute_params, sample_weight, synth
+    vox, sp = synth.value_noise(32, seed=5, zero_quantile=0.4)
+    g = oracle.BrickGrid(vox, sp)
+    tf, L = benchmark_tf()
+    r = Volxel3DRenderer(96, 64, low_res_preview=True)
+    r.setup_from_grid(g)
+    r.change_transfer_func(tf, L)
+    r.settings.render_mode = "dvr"
+    r.settings.dvr_jitter = True
+    r.settings.resolution_factor = 0.8
+    r.camera.pos = np.asarray(BENCH_CAM["cam_pos"], dtype=np.float64)
+    r.camera.view = np.asarray(BENCH_CAM["look_at"], dtype=np.float64)
+    r.restart_rendering()
+    lw, lh = math.floor(96 * (0.33 * 0.8)), math.floor(64 * (0.33 * 0.8))
+    assert (r.width, r.height) == (lw, lh) == (25, 16)
+    r.render(3)
+    assert r.frame_index == 3 and (r.width, r.height) == (lw, lh)
+    p = compute_params(r.settings, r.camera, r.volume, r.density_scale, lw, lh)
+    want, _ = oracle.render(p, g, tf, L, frame_index=2, sample_weight=0.0)
+    low = r.read_accum()
+    assert low.shape == (lh, lw, 4) and np.abs(low - want).max() <= 4e-6
+    disp = r.read_display()
+    assert disp.shape == (64, 96, 4)
+    want8, _ = oracle.blit(low, r.settings.exposure, r.settings.gamma)
+    ys = ((2 * np.arange(64) + 1) * lh) // (2 * 64)
+    xs = ((2 * np.arange(96) + 1) * lw) // (2 * 96)
+    assert np.abs(disp.astype(int) - want8[ys][:, xs].astype(int)).max() <= 1
+    r.render(4, in_flight=4)                       # frames 3,4 low; 5,6 at full size
+    fw, fh = math.floor(96 * 0.8), math.floor(64 * 0.8)
+    assert r.frame_index == 7 and (r.width, r.height) == (fw, fh) and r.resolution_factor == 1.0
+    p = compute_params(r.settings, r.camera, r.volume, r.density_scale, fw, fh)
+    prev = None
+    for f in (5, 6):
+        prev, _ = oracle.render(p, g, tf, L, frame_index=f, sample_weight=sample_weight(f), prev=prev)
+    assert np.abs(r.read_accum() - prev).max() <= 4e-6
+    r.restart_rendering()                          # any restart drops back to the preview size
+    assert (r.width, r.height, r.frame_index) == (lw, lh, 0)
+    r.render(1)
+    want, _ = oracle.render(compute_params(r.settings, r.camera, r.volume, r.density_scale, lw, lh), g, tf, L,
+                            frame_index=0, sample_weight=0.0)
+    assert np.abs(r.read_accum() - want).max() <= 4e-6
+
+
+def test_benchmark_runner_records(oracle):
+    """start_benchmark (viewer.ts:856-890) + the result record of viewer.ts:1229-1241"""
+    import copy
+    from volxel_amd import BENCHMARK_SETTINGS, Volxel3DRenderer, compute_params, sample_weight, synth
+    vox, sp = synth.value_noise(32, seed=5, zero_quantile=0.4)
+    g = oracle.BrickGrid(vox, sp)
+    shared = copy.deepcopy(BENCHMARK_SETTINGS)
+    shared["display"]["samples"] = 7
+    coll = {"sharedSettings": [shared],
+            "benchmarks": [{"renderMode": "raymarch", "settings": 0, "name": "rm"},
+                           {"renderMode": "dvr", "settings": 0, "name": "dvr", "zip": "noise"}]}
+    r = Volxel3DRenderer(96, 64)
+    r.setup_from_grid(g)
+    res = r.start_benchmark(coll, volumes={"noise": g})
+    assert [x["name"] for x in res] == ["rm", "dvr"]
+    for x in res:
+        assert x["totalTime"] > 0 and abs(x["timePerSample"] - x["totalTime"] / 8) < 1e-9   # frames 0..7
+        assert x["viewport"] == [0, 0, 0.8 * 96, 0.8 * 64] and x["settings"]["maxSamples"] == 7
+        assert "gfx950" in x["device"]["gpu"]["renderer"] and x["timestamp"].endswith("Z")
+    assert res[0]["settings"]["renderMode"] == "raymarch" and res[1]["settings"]["renderMode"] == "dvr"
+    # state after the run: frames 5..7 accumulated at 0.8 x canvas, then back to the caller's sizing
+    assert r.frame_index == 8
+    fw, fh = math.floor(96 * 0.8), math.floor(64 * 0.8)
+    with pytest.raises(Exception):
+        r.start_benchmark({"sharedSettings": [shared], "benchmarks": [{"settings": 0, "zip": "missing"}]})
+    # same scenario by hand == what the runner left in the accumulator
+    r2 = Volxel3DRenderer(96, 64, low_res_preview=True)
+    r2.setup_from_grid(g)
+    r2.restore_settings(shared)
+    r2.render_mode = "dvr"
+    r2.render(8)
+    p = compute_params(r2.settings, r2.camera, r2.volume, r2.density_scale, fw, fh)
+    from tests.common import benchmark_tf
+    tf, L = benchmark_tf()
+    prev = None
+    for f in (5, 6, 7):
+        prev, _ = oracle.render(p, g, tf, L, frame_index=f, sample_weight=sample_weight(f), prev=prev)
+    assert (r2.width, r2.height) == (fw, fh)
+    assert np.abs(r2.read_accum() - prev).max() <= 4e-6
 
 
 def test_error_contract():

@@ -271,3 +271,24 @@ def test_skip_mask_matches_oracle_and_is_exact(native_lib, oracle, case):
     b, cb = oracle.render(p, g, tf, L)
     assert np.array_equal(a, b)
     assert ca.samples < cb.samples and ca.samples + ca.skip_steps == cb.samples
+
+
+def test_benchmark_collection_schema():
+    """the VolxelBenchmark payload of data-benchmark-url (viewer.ts:72-82, public/benchmark.json)"""
+    import copy
+    from volxel_amd import BENCHMARK_SETTINGS, BENCHMARK_COLLECTION_MODES, ViewerSettings, verify_benchmark
+    coll = {"sharedSettings": [copy.deepcopy(BENCHMARK_SETTINGS)],
+            "benchmarks": [{"renderMode": m, "settings": 0} for m in BENCHMARK_COLLECTION_MODES]}
+    assert verify_benchmark(coll) is coll
+    for bad in ({"benchmarks": []}, {"sharedSettings": [], "benchmarks": [{"settings": 0}]},
+                {"sharedSettings": [BENCHMARK_SETTINGS], "benchmarks": [{"settings": 0, "renderMode": "fast"}]},
+                {"sharedSettings": [BENCHMARK_SETTINGS], "benchmarks": [{"settings": True}]},
+                {"sharedSettings": [{"version": "v2"}], "benchmarks": []}):
+        with pytest.raises(ValueError):
+            verify_benchmark(bad)
+    d = ViewerSettings().to_viewer_dict()
+    for k in ("densityMultiplier", "maxSamples", "debugHits", "volumeClipMin", "volumeClipMax", "showEnvironment",
+              "useEnv", "lightDir", "syncLightDir", "bounces", "gamma", "exposure", "sampleRange", "renderMode",
+              "resolutionFactor"):                      # viewer.ts:147-163
+        assert k in d
+    assert d["maxSamples"] == 2000 and d["renderMode"] == "default" and d["sampleRange"] == [0.0, 1.0]

@@ -6,6 +6,7 @@ Exports mirror volxel-3d-viewer/src/index.ts:1-4 for the parts on the path
 from .renderer import Volxel3DRenderer, VolxelError, compute_params, sample_weight  # noqa: F401
 from .transfer import (default_transfer_function, generate_transfer_function,  # noqa: F401
                        parse_transfer_function)
-from .settings import ViewerSettings, BENCHMARK_SETTINGS, verify_settings, load_settings  # noqa: F401
+from .settings import (ViewerSettings, BENCHMARK_SETTINGS, BENCHMARK_COLLECTION_MODES, verify_settings,  # noqa: F401
+                       verify_benchmark, load_settings)
 from .scene import Camera, Volume, Grid  # noqa: F401
 from .preprocessor import read_u16_stack_to_grid, read_dicoms_to_grid, BrickGridMessage  # noqa: F401

@@ -104,7 +104,9 @@ def load_library():
         "vx_finish": ([vp], i32),
         "vx_read_accum": ([vp, vp], i32),
         "vx_read_display": ([vp, vp, C.c_float, C.c_float], i32),
+        "vx_read_display_scaled": ([vp, vp, u32, u32, C.c_float, C.c_float], i32),
         "vx_slab_info": ([vp, P(u64), P(u32)], i32),
+        "vx_render_size": ([vp, P(u32), P(u32)], i32),
         "vx_slab_device_ptr": ([vp, P(vp)], i32),
         "vx_detile": ([vp, vp, vp], i32),
         "vx_get_counters": ([vp, P(VxCounters)], i32),

@@ -61,6 +61,8 @@ struct VxContext {
   size_t slab_quads = 0;
   float4* image = nullptr;
   uchar4* display = nullptr;
+  uint32_t display_cap = 0;  // pixels
+  size_t slab_cap = 0, image_cap = 0;
 
   // counters / timing
   DevCounters* dc = nullptr;   // one record per wave of the largest launch grid
@@ -143,18 +145,38 @@ static void update_tilemap(VxContext* c) {
 }
 
 static int alloc_framebuffers(VxContext* c) {
-  if (c->slab) (void)hipFree(c->slab);
-  if (c->image) (void)hipFree(c->image);
-  if (c->display) (void)hipFree(c->display);
-  c->slab = nullptr;
-  c->image = nullptr;
-  c->display = nullptr;
+  if (c->order && c->dc_waves) {  // the launch permutation belongs to the old grid: back to identity
+    std::vector<uint32_t> ident(c->dc_waves / 4);
+    for (size_t i = 0; i < ident.size(); ++i) ident[i] = (uint32_t)i;
+    VX_HIP(c, hipMemcpy(c->order, ident.data(), ident.size() * 4, hipMemcpyHostToDevice));
+    c->order_builds_left = 2;
+  }
+  // grow-only: the low-resolution preview (viewer.ts:1167-1188) resizes twice per restart
   update_tilemap(c);
   c->slab_quads = (size_t)c->tm.tiles_per_shard * 4096u;
   if (c->slab_quads == 0) return VX_OK;
-  VX_HIP(c, hipMalloc(&c->slab, c->slab_quads * sizeof(float4)));
-  VX_HIP(c, hipMalloc(&c->image, (size_t)c->W * c->H * sizeof(float4)));
-  VX_HIP(c, hipMalloc(&c->display, (size_t)c->W * c->H * sizeof(uchar4)));
+  size_t px = (size_t)c->W * c->H;
+  if (c->slab_quads > c->slab_cap) {
+    if (c->slab) (void)hipFree(c->slab);
+    c->slab = nullptr;
+    c->slab_cap = 0;
+    VX_HIP(c, hipMalloc(&c->slab, c->slab_quads * sizeof(float4)));
+    c->slab_cap = c->slab_quads;
+  }
+  if (px > c->image_cap) {
+    if (c->image) (void)hipFree(c->image);
+    c->image = nullptr;
+    c->image_cap = 0;
+    VX_HIP(c, hipMalloc(&c->image, px * sizeof(float4)));
+    c->image_cap = px;
+  }
+  if (px > c->display_cap) {
+    if (c->display) (void)hipFree(c->display);
+    c->display = nullptr;
+    c->display_cap = 0;
+    VX_HIP(c, hipMalloc(&c->display, px * sizeof(uchar4)));
+    c->display_cap = (uint32_t)px;
+  }
   VX_HIP(c, hipMemsetAsync(c->slab, 0, c->slab_quads * sizeof(float4), c->stream));
   return VX_OK;
 }
@@ -842,16 +864,39 @@ int vx_read_accum(VxContext* c, float* out) {
   return VX_OK;
 }
 
-int vx_read_display(VxContext* c, uint8_t* out, float exposure, float gamma) {
+int vx_read_display_scaled(VxContext* c, uint8_t* out, uint32_t ow, uint32_t oh, float exposure, float gamma) {
   if (!c || !out) return VX_ERR_INVALID;
+  if (ow == 0 || oh == 0 || (uint64_t)ow * oh > (1ull << 28)) {
+    c->err = "vx_read_display_scaled: bad canvas size";
+    return VX_ERR_INVALID;
+  }
   int rc = own_image(c);
   if (rc) return rc;
-  uint32_t n = c->W * c->H;
-  hipLaunchKernelGGL(blit_rgba8, dim3((n + 255) / 256), dim3(256), 0, c->stream, c->image, c->display, n,
-                     exposure, gamma);
+  uint32_t n = ow * oh;
+  if (n > c->display_cap) {
+    if (c->display) (void)hipFree(c->display);
+    c->display = nullptr;
+    c->display_cap = 0;
+    VX_HIP(c, hipMalloc(&c->display, (size_t)n * sizeof(uchar4)));
+    c->display_cap = n;
+  }
+  hipLaunchKernelGGL(blit_rgba8, dim3((n + 255) / 256), dim3(256), 0, c->stream, c->image, c->display, c->W, c->H,
+                     ow, oh, exposure, gamma);
   VX_HIP(c, hipGetLastError());
   VX_HIP(c, hipMemcpyAsync(out, c->display, (size_t)n * 4, hipMemcpyDeviceToHost, c->stream));
   VX_HIP(c, hipStreamSynchronize(c->stream));
+  return VX_OK;
+}
+
+int vx_read_display(VxContext* c, uint8_t* out, float exposure, float gamma) {
+  if (!c) return VX_ERR_INVALID;
+  return vx_read_display_scaled(c, out, c->W, c->H, exposure, gamma);
+}
+
+int vx_render_size(VxContext* c, uint32_t* w, uint32_t* h) {
+  if (!c) return VX_ERR_INVALID;
+  if (w) *w = c->W;
+  if (h) *h = c->H;
   return VX_OK;
 }
 

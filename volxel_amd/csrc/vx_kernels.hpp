@@ -243,12 +243,16 @@ VXD float hable(float x) {
   float den = fma_(D, F, x * (A * x + B));
   return num / den - E / F;
 }
+// out is ow x oh; the w x h image is sampled NEAREST (ow == w, oh == h: identity)
 __global__ __launch_bounds__(256) void blit_rgba8(const float4* __restrict__ image,
-                                                   uchar4* __restrict__ out, uint32_t n,
-                                                   float exposure, float gamma) {
+                                                   uchar4* __restrict__ out, uint32_t w, uint32_t h,
+                                                   uint32_t ow, uint32_t oh, float exposure, float gamma) {
   uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= n) return;
-  float4 a = image[i];
+  if (i >= ow * oh) return;
+  uint32_t x = i % ow, y = i / ow;
+  uint32_t sx = (uint32_t)(((uint64_t)(2u * x + 1u) * w) / (2ull * ow));
+  uint32_t sy = (uint32_t)(((uint64_t)(2u * y + 1u) * h) / (2ull * oh));
+  float4 a = image[sy * w + sx];
   float white = hable(11.2f), ig = 1.0f / gamma;
   float c[4] = {powf(hable(exposure * a.x) / white, ig), powf(hable(exposure * a.y) / white, ig),
                 powf(hable(exposure * a.z) / white, ig), a.w};

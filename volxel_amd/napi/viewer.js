@@ -128,9 +128,13 @@ class Camera { // representation/scene.ts
 }
 
 class Volxel3DDicomRenderer {
-  constructor({ width = 1920, height = 1080, device = 0, layout } = {}) {
+  /** width, height: the canvas.  lowResPreview reproduces the viewer's interactive sizing
+   *  (settings.resolutionFactor and the 0.33 ramp of viewer.ts:1167-1188); off = full-size frames. */
+  constructor({ width = 1920, height = 1080, device = 0, layout, lowResPreview = false } = {}) {
     this.ctx = native.create(device);            // throws when no GPU is visible
-    this.width = width; this.height = height;
+    this.canvasWidth = width; this.canvasHeight = height;
+    this.width = width; this.height = height;    // current render size
+    this.lowResPreview = lowResPreview; this.resolutionFactor = 1.0; // viewer.ts:131
     this.settings = { // viewer.ts:147-163 + [build] DVR parameters
       densityMultiplier: 1, maxSamples: 2000, debugHits: false, volumeClipMin: [0, 0, 0], volumeClipMax: [1, 1, 1],
       showEnvironment: true, useEnv: true, lightDir: [-1, -1, -1].map(v => v / Math.sqrt(3)), syncLightDir: false,
@@ -187,7 +191,15 @@ class Volxel3DDicomRenderer {
     native.uploadTransfer(this.ctx, data, length);
     this.frameIndex = 0;
   }
-  restartRendering() { this.frameIndex = 0; }   // viewer.ts:1155-1181
+  restartRendering() {                          // viewer.ts:1155-1181
+    if (this.lowResPreview) { this.resolutionFactor = 0.33; this.resizeFramebuffersToCanvas(); }
+    this.frameIndex = 0;
+  }
+  resizeFramebuffersToCanvas() {                // viewer.ts:925-949
+    const f = this.lowResPreview ? this.resolutionFactor * this.settings.resolutionFactor : 1.0;
+    const w = Math.max(1, Math.floor(this.canvasWidth * f)), h = Math.max(1, Math.floor(this.canvasHeight * f));
+    if (w !== this.width || h !== this.height) { this.width = w; this.height = h; native.resize(this.ctx, w, h); }
+  }
 
   restoreSettings(s) { // viewer.ts:704-713 (+ transfer/display/lighting closures)
     if (s.version !== 'v3') throw new Error(`Unsupported Settings Format Version: ${s.version}`);
@@ -246,8 +258,12 @@ class Volxel3DDicomRenderer {
   }
 
   render(frames = 1) { // viewer.ts:1183-1293
-    this.bindUniforms();
+    let bound = false;
     for (let i = 0; i < frames && this.frameIndex <= this.settings.maxSamples; ++i) {
+      if (this.lowResPreview && this.frameIndex >= LOW_RES_DURATION && this.resolutionFactor !== 1.0) {
+        this.resolutionFactor = 1.0; this.resizeFramebuffersToCanvas(); bound = false; // viewer.ts:1185-1188
+      }
+      if (!bound) { this.bindUniforms(); bound = true; }
       const f = this.frameIndex;
       const w = f < LOW_RES_DURATION ? 0 : (f - LOW_RES_DURATION) / (f - LOW_RES_DURATION + 1); // viewer.ts:1356
       native.renderFrame(this.ctx, f, w);
@@ -256,9 +272,9 @@ class Volxel3DDicomRenderer {
   }
   finish() { native.finish(this.ctx); }
   readAccum() { const o = new Float32Array(this.width * this.height * 4); native.readAccum(this.ctx, o); return o; }
-  readDisplay() {
-    const o = new Uint8Array(this.width * this.height * 4);
-    native.readDisplay(this.ctx, o, this.settings.exposure, this.settings.gamma);
+  readDisplay() { // the blit to the canvas (NEAREST, viewer.ts:310-311,1253-1265)
+    const o = new Uint8Array(this.canvasWidth * this.canvasHeight * 4);
+    native.readDisplayScaled(this.ctx, o, this.canvasWidth, this.canvasHeight, this.settings.exposure, this.settings.gamma);
     return o;
   }
   counters() { return native.getCounters(this.ctx); }

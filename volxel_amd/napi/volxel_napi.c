@@ -225,7 +225,10 @@ static napi_value n_read_accum(napi_env env, napi_callback_info info) {
   if (!c) return NULL;
   void* d;
   size_t n;
+  uint32_t w = 0, h = 0;
   if (!typed(env, a[1], napi_float32_array, &d, &n)) return NULL;
+  vx_render_size(c, &w, &h);
+  if (n < (size_t)w * h * 4) return throw_msg(env, "readAccum: buffer smaller than width*height*4 floats");
   if (vx_read_accum(c, (float*)d) != VX_OK) return throw_msg(env, vx_last_error(c));
   return NULL;
 }
@@ -241,7 +244,31 @@ static napi_value n_read_display(napi_env env, napi_callback_info info) {
   if (!typed(env, a[1], napi_uint8_array, &d, &n)) return NULL;
   NAPI_OK(napi_get_value_double(env, a[2], &ex));
   NAPI_OK(napi_get_value_double(env, a[3], &ga));
+  uint32_t w = 0, h = 0;
+  vx_render_size(c, &w, &h);
+  if (n < (size_t)w * h * 4) return throw_msg(env, "readDisplay: buffer smaller than width*height*4 bytes");
   if (vx_read_display(c, (uint8_t*)d, (float)ex, (float)ga) != VX_OK) return throw_msg(env, vx_last_error(c));
+  return NULL;
+}
+
+/* readDisplayScaled(ctx, Uint8Array out, outW, outH, exposure, gamma): the blit to a canvas */
+static napi_value n_read_display_scaled(napi_env env, napi_callback_info info) {
+  napi_value a[6];
+  if (!get_args(env, info, 6, a)) return NULL;
+  VxContext* c = get_ctx(env, a[0]);
+  if (!c) return NULL;
+  void* d;
+  size_t n;
+  uint32_t ow, oh;
+  double ex, ga;
+  if (!typed(env, a[1], napi_uint8_array, &d, &n)) return NULL;
+  NAPI_OK(napi_get_value_uint32(env, a[2], &ow));
+  NAPI_OK(napi_get_value_uint32(env, a[3], &oh));
+  NAPI_OK(napi_get_value_double(env, a[4], &ex));
+  NAPI_OK(napi_get_value_double(env, a[5], &ga));
+  if (n < (size_t)ow * oh * 4) return throw_msg(env, "readDisplayScaled: buffer smaller than outW*outH*4 bytes");
+  if (vx_read_display_scaled(c, (uint8_t*)d, ow, oh, (float)ex, (float)ga) != VX_OK)
+    return throw_msg(env, vx_last_error(c));
   return NULL;
 }
 
@@ -425,7 +452,8 @@ static napi_value init(napi_env env, napi_value exports) {
       {"create", n_create}, {"destroy", n_destroy}, {"uploadVolume", n_upload_volume},
       {"uploadTransfer", n_upload_transfer}, {"setParams", n_set_params}, {"sizeofParams", n_sizeof_params},
       {"resize", n_resize}, {"setLayout", n_set_layout}, {"renderFrame", n_render_frame}, {"finish", n_finish},
-      {"readAccum", n_read_accum}, {"readDisplay", n_read_display}, {"getCounters", n_get_counters},
+      {"readAccum", n_read_accum}, {"readDisplay", n_read_display},
+      {"readDisplayScaled", n_read_display_scaled}, {"getCounters", n_get_counters},
       {"resetCounters", n_reset_counters}, {"version", n_version}, {"buildBrickGrid", n_build_brick_grid},
       {"readDicomsToGrid", n_read_dicoms_to_grid}};
   for (size_t i = 0; i < sizeof fns / sizeof fns[0]; ++i) {

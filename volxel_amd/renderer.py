@@ -108,7 +108,12 @@ class Volxel3DRenderer:
     """Headless counterpart of the `<volxel-3d-viewer>` element's render core."""
 
     def __init__(self, width: int = 1920, height: int = 1080, device: int = 0,
-                 shard_rank: int = 0, shard_count: int = 1, layout: int | None = None):
+                 shard_rank: int = 0, shard_count: int = 1, layout: int | None = None,
+                 low_res_preview: bool = False):
+        """width, height: the canvas.  low_res_preview=True reproduces the viewer's interactive
+        ramp (viewer.ts:1167-1188): after every restart the first `low_resolution_duration` frames
+        are rendered at 0.33 x the canvas and shown NEAREST-magnified; a headless caller that wants
+        full-size frames from frame 0 (tests, bench.py) leaves it off."""
         self._lib = _abi.load_library()
         self._ctx = C.c_void_p()
         rc = self._lib.vx_create(int(device), C.byref(self._ctx))
@@ -122,9 +127,12 @@ class Volxel3DRenderer:
         self.density_scale = 1.0
         self.env_strength = 1.0
         self.frame_index = 0
-        self.width, self.height = int(width), int(height)
+        self.canvas_width, self.canvas_height = int(width), int(height)
+        self.width, self.height = int(width), int(height)      # current render size
         self.shard_rank, self.shard_count = shard_rank, shard_count
         self.low_resolution_duration = LOW_RESOLUTION_DURATION
+        self.low_res_preview = bool(low_res_preview)
+        self.resolution_factor = 1.0                           # viewer.ts:131, the ramp state
         if layout is not None:
             self._check(self._lib.vx_set_layout(self._ctx, int(layout)))
         self._check(self._lib.vx_resize(self._ctx, self.width, self.height))
@@ -198,11 +206,22 @@ class Volxel3DRenderer:
 
     # -- viewer.ts:1155-1181 ------------------------------------------------------------
     def restart_rendering(self):
+        if self.low_res_preview:                               # viewer.ts:1176-1178
+            self.resolution_factor = 0.33
+            self._resize_framebuffers_to_canvas()
         self.frame_index = 0
 
+    def _resize_framebuffers_to_canvas(self):                  # viewer.ts:925-949
+        f = self.resolution_factor * self.settings.resolution_factor if self.low_res_preview else 1.0
+        w = max(1, math.floor(self.canvas_width * f))
+        h = max(1, math.floor(self.canvas_height * f))
+        if (w, h) != (self.width, self.height):
+            self.width, self.height = w, h
+            self._check(self._lib.vx_resize(self._ctx, w, h))
+
     def resize(self, width: int, height: int):
-        self.width, self.height = int(width), int(height)
-        self._check(self._lib.vx_resize(self._ctx, self.width, self.height))
+        self.canvas_width, self.canvas_height = int(width), int(height)
+        self._resize_framebuffers_to_canvas()
         self.restart_rendering()
 
     # -- viewer.ts:704-713 restoreSettings ---------------------------------------------
@@ -251,6 +270,21 @@ class Volxel3DRenderer:
         """Render `frames` accumulation samples (the body of render() while
         frameIndex <= maxSamples).  Asynchronous; call finish() or a read_* to wait.
         in_flight > 1 renders that many frames concurrently (vx_render_frames): same bits."""
+        if self.low_res_preview and (self.frame_index < self.low_resolution_duration or self.resolution_factor != 1.0):
+            # the ramp changes the framebuffer size at frame low_resolution_duration: step up to it
+            while frames > 0 and self.frame_index <= self.settings.max_samples:
+                if self.frame_index >= self.low_resolution_duration:
+                    if self.resolution_factor != 1.0:          # viewer.ts:1185-1188
+                        self.resolution_factor = 1.0
+                        self._resize_framebuffers_to_canvas()
+                    break
+                self.bind_uniforms()
+                self._check(self._lib.vx_render_frame(self._ctx, self.frame_index, 0.0))
+                self.frame_index += 1
+                frames -= 1
+            if frames == 0:
+                return
+            rebind = True
         if rebind:
             self.bind_uniforms()
         if in_flight > 1 and frames > 1:
@@ -276,11 +310,75 @@ class Volxel3DRenderer:
         self._check(self._lib.vx_read_accum(self._ctx, out.ctypes.data))
         return out
 
-    def read_display(self) -> np.ndarray:  # blit pass, viewer.ts:1259-1265
-        out = np.empty((self.height, self.width, 4), dtype=np.uint8)
-        self._check(self._lib.vx_read_display(self._ctx, out.ctypes.data,
-                                              float(self.settings.exposure), float(self.settings.gamma)))
+    def read_display(self) -> np.ndarray:  # blit pass to the canvas, viewer.ts:1253-1265
+        out = np.empty((self.canvas_height, self.canvas_width, 4), dtype=np.uint8)
+        self._check(self._lib.vx_read_display_scaled(self._ctx, out.ctypes.data, self.canvas_width,
+                                                     self.canvas_height, float(self.settings.exposure),
+                                                     float(self.settings.gamma)))
         return out
+
+    # -- viewer.ts:856-890,1213-1252: the data-benchmark-url runner ------------------------
+    def start_benchmark(self, collection: dict, volumes: dict | None = None, progress=None) -> list:
+        """Run a VolxelBenchmark collection (public/benchmark.json) and return the list of
+        VolxelBenchmarkResult records the viewer would hand to saveBenchmark.
+
+        Per entry, as startBenchmark/singleBenchmark do: optional volume switch, restoreSettings,
+        renderMode, restart; then frames 0..maxSamples are rendered one by one with gl.finish()
+        (vx_finish) inside the timed region, on the viewer's framebuffer sizing (resolutionFactor and
+        the 0.33 preview for the first frames).  `volumes` maps an entry's "zip" string to a brick
+        grid message (ZIP/DICOM container I/O is outside the path); entries without one keep the
+        current volume.  Times are milliseconds like performance.now()."""
+        import datetime
+        import os
+        import platform
+        import time
+        from .settings import verify_benchmark
+        verify_benchmark(collection)
+        name, cus, mem = self.device_info()
+        device = {"platform": platform.platform(), "userAgent": "volxel_amd " + self._lib.vx_version().decode(),
+                  "deviceMemory": mem / 2 ** 30, "hardwareConcurrency": os.cpu_count(),
+                  "screen": {"width": self.canvas_width, "height": self.canvas_height, "pixelRatio": 1},
+                  "gpu": {"vendor": "AMD", "renderer": name.strip(), "version": "HIP",
+                          "shadingLanguageVersion": "gfx950", "supportedExtensions": [], "computeUnits": cus}}
+        results = []
+        saved_preview = self.low_res_preview
+        self.low_res_preview = True
+        try:
+            for entry in collection["benchmarks"]:
+                if entry.get("zip") is not None:
+                    if not volumes or entry["zip"] not in volumes:
+                        raise VolxelError(f"benchmark volume not provided: {entry['zip']}")
+                    self.setup_from_grid(volumes[entry["zip"]])
+                if entry.get("env") is not None:
+                    raise VolxelError("benchmark entry asks for an environment map URL; pass the decoded "
+                                      "map with set_environment() before the run")
+                st = entry["settings"]
+                self.restore_settings(collection["sharedSettings"][st] if isinstance(st, int) else st)
+                if entry.get("renderMode"):
+                    self.render_mode = entry["renderMode"]
+                self.restart_rendering()
+                total = 0.0
+                while self.frame_index <= self.settings.max_samples:      # viewer.ts:1194
+                    t0 = time.perf_counter()
+                    self.render(1)
+                    self.finish()                                         # viewer.ts:1213-1218
+                    total += (time.perf_counter() - t0) * 1e3
+                    if progress and self.frame_index % 100 == 0:
+                        progress(entry.get("name"), self.frame_index, self.settings.max_samples)
+                rf = self.settings.resolution_factor
+                results.append({
+                    "name": entry.get("name"), "settings": self.settings.to_viewer_dict(),
+                    "timePerSample": total / self.frame_index, "totalTime": total,
+                    "viewport": [0, 0, rf * self.canvas_width, rf * self.canvas_height],
+                    "device": device,
+                    "timestamp": datetime.datetime.now(datetime.timezone.utc).isoformat().replace("+00:00", "Z"),
+                })
+        finally:
+            self.low_res_preview = saved_preview
+            if not saved_preview:
+                self.resolution_factor = 1.0
+                self._resize_framebuffers_to_canvas()
+        return results
 
     # -- measurement hooks (viewer.ts:1213-1252 benchmark harness) -----------------------
     def counters(self):

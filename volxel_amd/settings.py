@@ -37,6 +37,23 @@ class ViewerSettings:  # settings.ts:45-61, defaults viewer.ts:147-163
     phong: tuple = (0.3, 0.7, 0.4, 32.0)  # ka, kd, ks, shininess
 
 
+    def to_viewer_dict(self) -> dict:
+        """The viewer's own `settings` object (viewer.ts:147-163) as JSON.stringify would emit it
+        into a VolxelBenchmarkResult (viewer.ts:1233-1236); [build] fields under their JS-host names."""
+        return {
+            "densityMultiplier": self.density_multiplier, "maxSamples": self.max_samples,
+            "debugHits": self.debug_hits, "volumeClipMin": list(self.volume_clip_min),
+            "volumeClipMax": list(self.volume_clip_max), "showEnvironment": self.show_environment,
+            "useEnv": self.use_env, "lightDir": list(self.light_dir), "syncLightDir": self.sync_light_dir,
+            "bounces": self.bounces, "gamma": self.gamma, "exposure": self.exposure,
+            "sampleRange": list(self.sample_range), "renderMode": self.render_mode,
+            "resolutionFactor": self.resolution_factor,
+            "dvrStepVoxels": self.dvr_step_voxels, "dvrErtEpsilon": self.dvr_ert_epsilon,
+            "dvrJitter": self.dvr_jitter, "dvrMaxSteps": self.dvr_max_steps,
+            "dvrSkipEmpty": self.dvr_skip_empty, "phong": list(self.phong),
+        }
+
+
 def _is_num(x):
     return isinstance(x, (int, float)) and not isinstance(x, bool)
 
@@ -94,6 +111,30 @@ def load_settings(text_or_path):  # settings.ts:153-165
         with open(text_or_path) as f:
             text = f.read()
     return verify_settings(json.loads(text))
+
+
+def verify_benchmark(b):  # the VolxelBenchmark type, viewer.ts:72-82 (data-benchmark-url payload)
+    if (not isinstance(b, dict) or not isinstance(b.get("sharedSettings"), list)
+            or not isinstance(b.get("benchmarks"), list)):
+        raise ValueError("Malformed benchmark collection.")
+    for s in b["sharedSettings"]:
+        verify_settings(s)
+    for e in b["benchmarks"]:
+        st = e.get("settings") if isinstance(e, dict) else None
+        if isinstance(st, bool) or not isinstance(st, (int, dict)):
+            raise ValueError("Malformed benchmark entry: settings must be an index or a settings export.")
+        if isinstance(st, int):
+            if not 0 <= st < len(b["sharedSettings"]):
+                raise ValueError("Benchmark entry refers to a missing shared settings index.")
+        else:
+            verify_settings(st)
+        if e.get("renderMode") is not None and e["renderMode"] not in RENDER_MODES:
+            raise ValueError(f"Unrecognized render mode provided: {e['renderMode']}")
+    return b
+
+
+# public/benchmark.json:86-99: the three reference scenarios, all on shared settings 0
+BENCHMARK_COLLECTION_MODES = ("default", "no_dda", "raymarch")
 
 
 # public/benchmark.json:5-85 -- the only reference-supplied render inputs.
