@@ -71,8 +71,10 @@ def cpu_baseline(r, msg, crop=(1920, 1080)):
     crop = (min(crop[0], W), min(crop[1], H))
     x0, y0 = (W - crop[0]) // 2, (H - crop[1]) // 2
     vol = O.make_volume(msg)
+    env = O.Environment(r.environment.floats, r.environment.width, r.environment.height) if r.environment else None
     t0 = time.perf_counter()
-    _, c = O.render(p, vol, tf, L, frame_index=0, rect=(x0, x0 + crop[0], y0, y0 + crop[1]), threads=threads)
+    _, c = O.render(p, vol, tf, L, frame_index=0, rect=(x0, x0 + crop[0], y0, y0 + crop[1]), threads=threads,
+                    env=env)
     dt = time.perf_counter() - t0
     return {"value": round(c.samples / dt / 1e9, 5), "unit": "Gsamples/s", "cores": threads, "kind": "port",
             "sample": f"centred {crop[0]}x{crop[1]} crop of the same frame, {c.samples} samples in {dt:.2f} s "

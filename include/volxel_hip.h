@@ -170,6 +170,15 @@ int vx_set_layout(VxContext* ctx, int layout);
  *      rgba = length x 4 floats, sampled NEAREST + CLAMP_TO_EDGE (viewer.ts:386-389). */
 int vx_upload_transfer(VxContext* ctx, const float* rgba, uint32_t length);
 
+/* ---- environment map: replaces `new Environment(gl, env)` (representation/environment.ts:15-61,
+ *      viewer.ts:1076-1077): rgba = width*height*4 floats with row 0 = TOP, exactly the `floats` of
+ *      WasmWorkerMessageEnvReturn (the library applies the UNPACK_FLIP_Y_WEBGL of environment.ts:30-32);
+ *      builds the 512x512 importance map (shaders/envSetup.frag, 8x8 taps per texel) and its mip
+ *      chain on the device.  Needed before VxParams.use_env = 1.  Passing rgba = NULL removes it. */
+int vx_upload_environment(VxContext* ctx, const float* rgba, uint32_t width, uint32_t height);
+/* test hook: the importance pyramid, 349525 floats (levels 0..9 of the 512^2 map back to back) */
+int vx_debug_read_importance(VxContext* ctx, float* out);
+
 /* ---- uniforms: replaces bindUniforms + Camera.bindAsUniforms (viewer.ts:1295-1357,
  *      scene.ts:53-56). */
 int vx_set_params(VxContext* ctx, const VxParams* params);

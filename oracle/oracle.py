@@ -49,6 +49,52 @@ class VxoVolume(C.Structure):
                 ("index_extent", C.c_uint32 * 3)]
 
 
+class VxoEnvironment(C.Structure):
+    _fields_ = [("texture", C.c_void_p), ("width", C.c_uint32), ("height", C.c_uint32),
+                ("importance", C.c_void_p)]
+
+
+IMP_DIM, IMP_LEVELS, IMP_FLOATS = 512, 10, 349525
+
+
+class Environment:
+    """environment.ts: base map (row 0 = top, RGBA float) -> flipped texture + importance pyramid"""
+
+    def __init__(self, floats, width, height):
+        L = lib()
+        src = np.ascontiguousarray(floats, dtype=np.float32).reshape(height, width, 4)
+        self.width, self.height = int(width), int(height)
+        self.texture = np.empty_like(src)
+        L.vxo_env_flip_rows(src.ctypes.data, width, height, self.texture.ctypes.data)
+        self.importance = np.empty(IMP_FLOATS, dtype=np.float32)
+        L.vxo_env_build_importance(self.texture.ctypes.data, width, height, self.importance.ctypes.data)
+        self.c = VxoEnvironment(self.texture.ctypes.data, width, height, self.importance.ctypes.data)
+
+    def level(self, k):
+        L = lib()
+        n = IMP_DIM >> k
+        o = L.vxo_imp_offset(k)
+        return self.importance[o:o + n * n].reshape(n, n)
+
+    def sample(self, u0, u1, strength=1.0):
+        wi, lp = (C.c_float * 3)(), (C.c_float * 4)()
+        lib().vxo_env_sample(C.byref(self.c), strength, u0, u1, wi, lp)
+        return np.array(wi[:], dtype=np.float32), np.array(lp[:], dtype=np.float32)
+
+    def lookup(self, d, strength=1.0):
+        rgb = (C.c_float * 3)()
+        lib().vxo_env_lookup(C.byref(self.c), strength, (C.c_float * 3)(*d), rgb)
+        return np.array(rgb[:], dtype=np.float32)
+
+    def pdf(self, d, strength=1.0):
+        return lib().vxo_env_pdf(C.byref(self.c), strength, (C.c_float * 3)(*d))
+
+    def texture_at(self, u, v):
+        rgb = (C.c_float * 3)()
+        lib().vxo_env_texture(C.byref(self.c), u, v, rgb)
+        return np.array(rgb[:], dtype=np.float32)
+
+
 class VxoCounters(C.Structure):
     _fields_ = [("samples", C.c_uint64), ("rays", C.c_uint64), ("pixels", C.c_uint64),
                 ("skip_steps", C.c_uint64), ("grad_samples", C.c_uint64)]
@@ -112,6 +158,16 @@ def lib():
     L.vxo_render.argtypes = [P(VxParams), u32, f32, P(VxoVolume), vp, u32, vp, vp, i32, i32, i32,
                              i32, P(VxoCounters)]
     L.vxo_render.restype = C.c_int
+    L.vxo_render_env.argtypes = [P(VxParams), u32, f32, P(VxoVolume), vp, u32, P(VxoEnvironment), vp, vp, i32,
+                                 i32, i32, i32, P(VxoCounters)]
+    L.vxo_render_env.restype = C.c_int
+    L.vxo_imp_offset.argtypes = [u32]; L.vxo_imp_offset.restype = u32
+    L.vxo_env_flip_rows.argtypes = [vp, u32, u32, vp]
+    L.vxo_env_texture.argtypes = [P(VxoEnvironment), f32, f32, P(f32)]
+    L.vxo_env_build_importance.argtypes = [vp, u32, u32, vp]
+    L.vxo_env_sample.argtypes = [P(VxoEnvironment), f32, f32, f32, P(f32), P(f32)]
+    L.vxo_env_lookup.argtypes = [P(VxoEnvironment), f32, P(f32), P(f32)]
+    L.vxo_env_pdf.argtypes = [P(VxoEnvironment), f32, P(f32)]; L.vxo_env_pdf.restype = f32
     L.vxo_primary_ray.argtypes = [P(VxParams), u32, i32, i32, P(f32), P(f32)]
     L.vxo_blit.argtypes = [vp, u32, f32, f32, vp, vp]
     L.vxo_skip_level.argtypes = [P(VxoVolume)]; L.vxo_skip_level.restype = C.c_int
@@ -218,7 +274,7 @@ def copy_params(src) -> VxParams:
 
 
 def render(params, grid, tf, tf_len, frame_index=0, sample_weight=0.0, prev=None, rect=None,
-           threads=None):
+           threads=None, env=None):
     """fragment.frag main over the image (or rect = (x0,x1,y0,y1)); returns (rgba, counters)."""
     L = lib()
     p = copy_params(params)
@@ -235,10 +291,11 @@ def render(params, grid, tf, tf_len, frame_index=0, sample_weight=0.0, prev=None
 
     def work(i):
         c = VxoCounters()
-        rc = L.vxo_render(C.byref(p), frame_index, sample_weight, C.byref(vol), tf.ctypes.data,
-                          tf_len, prev.ctypes.data if prev is not None else None, out.ctypes.data,
-                          x0, x1, int(bands[i]), int(bands[i + 1]), C.byref(c))
-        assert rc == 0
+        rc = L.vxo_render_env(C.byref(p), frame_index, sample_weight, C.byref(vol), tf.ctypes.data,
+                              tf_len, C.byref(env.c) if env is not None else None,
+                              prev.ctypes.data if prev is not None else None, out.ctypes.data,
+                              x0, x1, int(bands[i]), int(bands[i + 1]), C.byref(c))
+        assert rc == 0, rc
         return c
 
     if threads == 1:

@@ -507,6 +507,7 @@ typedef struct {
   const uint32_t* skip_bits; /* NULL: skipping off */
   int skip_level;
   uint32_t skip_dims[3];
+  const VxoEnvironment* env; /* NULL: directional light (u_use_env < 1) */
 } Ctx;
 
 typedef struct { v3 o, d; } Ray;
@@ -825,20 +826,145 @@ static v3 sample_phase_hg(v3 dir, float g, float u0, float u1) {
   return align3(dir, V3(sin_t * cosf(phi), sin_t * sinf(phi), cos_t));
 }
 
-/* environment.glsl:19-22, directional branch.  [build] pow() of a negative base is
- * undefined in GLSL ES 3.00; the base is clamped at 0 first (quirk Q16). */
+/* ---- environment map ------------------------------------------------------------------ */
+uint32_t vxo_imp_offset(uint32_t level) {
+  uint32_t o = 0;
+  for (uint32_t k = 0; k < level; ++k) o += (VXO_IMP_DIM >> k) * (VXO_IMP_DIM >> k);
+  return o;
+}
+/* environment.ts:30-32 UNPACK_FLIP_Y_WEBGL: source row 0 (top) becomes the last texel row */
+void vxo_env_flip_rows(const float* src, uint32_t w, uint32_t h, float* dst) {
+  for (uint32_t y = 0; y < h; ++y) memcpy(dst + (size_t)(h - 1 - y) * w * 4, src + (size_t)y * w * 4, (size_t)w * 16);
+}
+/* texture(u_envmap, uv): GL ES 3.0 section 3.8.10 LINEAR, wrap REPEAT / CLAMP_TO_EDGE
+ * (environment.ts:22-26) */
+static void env_texture(const float* tex, uint32_t w, uint32_t h, float u, float v, float rgb[3]) {
+  float x = fmaf(u, (float)w, -0.5f), y = fmaf(v, (float)h, -0.5f);
+  float fx = floorf(x), fy = floorf(y);
+  float a = x - fx, b = y - fy;
+  int32_t i0 = f2i(fx), j0 = f2i(fy);
+  int32_t W = (int32_t)w, H = (int32_t)h;
+  int32_t i1 = i0 + 1, j1 = j0 + 1;
+  i0 %= W; if (i0 < 0) i0 += W;
+  i1 %= W; if (i1 < 0) i1 += W;
+  j0 = j0 < 0 ? 0 : (j0 > H - 1 ? H - 1 : j0);
+  j1 = j1 < 0 ? 0 : (j1 > H - 1 ? H - 1 : j1);
+  const float* t00 = tex + ((size_t)j0 * w + i0) * 4;
+  const float* t10 = tex + ((size_t)j0 * w + i1) * 4;
+  const float* t01 = tex + ((size_t)j1 * w + i0) * 4;
+  const float* t11 = tex + ((size_t)j1 * w + i1) * 4;
+  for (int c = 0; c < 3; ++c) {
+    float lo = fmaf(t10[c], a, t00[c] * (1.0f - a)); /* mix(t00, t10, a) */
+    float hi = fmaf(t11[c], a, t01[c] * (1.0f - a));
+    rgb[c] = fmaf(hi, b, lo * (1.0f - b));
+  }
+}
+void vxo_env_texture(const VxoEnvironment* e, float u, float v, float rgb[3]) {
+  env_texture(e->texture, e->width, e->height, u, v, rgb);
+}
+/* envSetup.frag:26-41 dispatched over 512x512 with 8x8 samples per texel (environment.ts:9-10,
+ * 49-56), then generateMipmap (environment.ts:58-60) */
+void vxo_env_build_importance(const float* tex, uint32_t w, uint32_t h, float* pyr) {
+  const int ns = 8;
+  const float out_size = (float)(VXO_IMP_DIM * ns), inv_samples = 1.0f / (float)(ns * ns);
+  for (uint32_t py = 0; py < VXO_IMP_DIM; ++py)
+    for (uint32_t px = 0; px < VXO_IMP_DIM; ++px) {
+      float imp = 0.0f;
+      for (int y = 0; y < ns; ++y)
+        for (int x = 0; x < ns; ++x) {
+          float u = ((float)(px * ns) + ((float)x + 0.5f)) / out_size;
+          float v = ((float)(py * ns) + ((float)y + 0.5f)) / out_size;
+          float rgb[3];
+          env_texture(tex, w, h, u, v, rgb);
+          imp += luma(V3(rgb[0], rgb[1], rgb[2]));
+        }
+      pyr[(size_t)py * VXO_IMP_DIM + px] = imp * inv_samples;
+    }
+  for (uint32_t k = 1; k < VXO_IMP_LEVELS; ++k) {
+    uint32_t n = VXO_IMP_DIM >> k, m = n * 2;
+    const float* src = pyr + vxo_imp_offset(k - 1);
+    float* dst = pyr + vxo_imp_offset(k);
+    for (uint32_t y = 0; y < n; ++y)
+      for (uint32_t x = 0; x < n; ++x) {
+        float a = src[(size_t)(2 * y) * m + 2 * x], b = src[(size_t)(2 * y) * m + 2 * x + 1];
+        float c = src[(size_t)(2 * y + 1) * m + 2 * x], d = src[(size_t)(2 * y + 1) * m + 2 * x + 1];
+        dst[(size_t)y * n + x] = (((a + b) + c) + d) * 0.25f;
+      }
+  }
+}
+static inline float imp_fetch(const VxoEnvironment* e, int32_t x, int32_t y, int mip) {
+  int32_t n = (int32_t)(VXO_IMP_DIM >> mip);
+  if (x < 0 || y < 0 || x >= n || y >= n) return 0.0f; /* texelFetch out of range */
+  return e->importance[vxo_imp_offset((uint32_t)mip) + (size_t)y * n + x];
+}
+/* environment.glsl:19-27 */
+void vxo_env_lookup(const VxoEnvironment* e, float env_strength, const float dir[3], float rgb[3]) {
+  float u = atan2f(dir[2], dir[0]) / (2.0f * M_PI_F) + 0.5f;
+  float v = 1.0f - acosf(dir[1]) / M_PI_F;
+  env_texture(e->texture, e->width, e->height, u, v, rgb);
+  for (int c = 0; c < 3; ++c) rgb[c] = env_strength * rgb[c];
+}
+/* environment.glsl:29-79 */
+void vxo_env_sample(const VxoEnvironment* e, float env_strength, float u0, float u1, float w_i[3],
+                    float le_pdf[4]) {
+  int32_t px = 0, py = 0;
+  float sx = u0, sy = u1;
+  for (int mip = (int)VXO_IMP_LEVELS - 2; mip >= 0; --mip) {
+    px *= 2; py *= 2;
+    float w[4] = {imp_fetch(e, px, py, mip), imp_fetch(e, px + 1, py, mip), imp_fetch(e, px, py + 1, mip),
+                  imp_fetch(e, px + 1, py + 1, mip)};
+    float q[2] = {w[0] + w[2], w[1] + w[3]};
+    int off_x;
+    float d = q[0] / gl_max(1e-8f, q[0] + q[1]);
+    if (sx < d) { off_x = 0; sx = sx / d; }
+    else { off_x = 1; sx = (sx - d) / (1.0f - d); }
+    px += off_x;
+    float ee = w[off_x] / q[off_x];
+    if (sy < ee) { sy = sy / ee; }
+    else { py += 1; sy = (sy - ee) / (1.0f - ee); }
+  }
+  const float inv_dim = 1.0f / (float)VXO_IMP_DIM;
+  float uvx = ((float)px + sx) * inv_dim, uvy = ((float)py + sy) * inv_dim;
+  float theta = gl_clamp(1.0f - uvy, 0.0f, 1.0f) * M_PI_F;
+  float phi = (gl_clamp(uvx, 0.0f, 1.0f) * 2.0f - 1.0f) * M_PI_F;
+  float sin_t = sinf(theta);
+  w_i[0] = sin_t * cosf(phi); w_i[1] = cosf(theta); w_i[2] = sin_t * sinf(phi);
+  float rgb[3];
+  env_texture(e->texture, e->width, e->height, uvx, uvy, rgb);
+  float avg_w = imp_fetch(e, 0, 0, (int)VXO_IMP_LEVELS - 1);
+  float pdf = imp_fetch(e, px, py, 0) / avg_w;
+  for (int c = 0; c < 3; ++c) le_pdf[c] = env_strength * rgb[c];
+  le_pdf[3] = pdf * INV_4PI;
+}
+/* environment.glsl:82-86 */
+float vxo_env_pdf(const VxoEnvironment* e, float env_strength, const float dir[3]) {
+  float rgb[3];
+  vxo_env_lookup(e, env_strength, dir, rgb);
+  float avg_w = imp_fetch(e, 0, 0, (int)VXO_IMP_LEVELS - 1);
+  return luma(V3(rgb[0], rgb[1], rgb[2])) / avg_w * INV_4PI;
+}
+
+/* environment.glsl:19-27.  Directional branch: [build] pow() of a negative base is undefined in
+ * GLSL ES 3.00; the base is clamped at 0 first (quirk Q16). */
 static v3 lookup_environment(Ctx* k, v3 dir) {
+  if (k->p->use_env > 0 && k->env) {
+    float d[3] = {dir.x, dir.y, dir.z}, rgb[3];
+    vxo_env_lookup(k->env, k->p->env_strength, d, rgb);
+    return V3(rgb[0], rgb[1], rgb[2]);
+  }
   v3 nl = V3(-k->p->light_dir[0], -k->p->light_dir[1], -k->p->light_dir[2]);
   float c = gl_max(dot3(dir, nl), 0.0f);
   float s = gl_clamp(powf(c, 300.0f), 0.0f, 1.0f);
   float e = k->p->env_strength * fmaf(s, 4.0f, 0.01f);
   return V3(e, e, e);
 }
-/* environment.glsl:82-86 -- only reached with an environment map (avg_w comes from the
- * importance map); with the directional light [build] the pdf of hitting a delta light by
- * phase sampling is 0. */
+/* environment.glsl:82-86 -- with the directional light [build] the pdf of hitting a delta light by
+ * phase sampling is 0 (avg_w would come from an importance map that does not exist). */
 static inline float pdf_environment(Ctx* k, v3 dir) {
-  (void)k; (void)dir;
+  if (k->p->use_env > 0 && k->env) {
+    float d[3] = {dir.x, dir.y, dir.z};
+    return vxo_env_pdf(k->env, k->p->env_strength, d);
+  }
   return 0.0f;
 }
 
@@ -855,19 +981,24 @@ static void trace_path(Ctx* k, Ray ray, uint32_t s[4], float out[4]) {
     ray.o = madd3(ray.o, t, ray.d); /* :88 */
     /* :92 sample_environment(rng2(seed), w_i): two draws consumed even with the
        directional light (environment.glsl:30-33) */
-    (void)vxo_rng(s);
-    (void)vxo_rng(s);
+    float e0 = vxo_rng(s), e1 = vxo_rng(s);
     v3 w_i = V3(-p->light_dir[0], -p->light_dir[1], -p->light_dir[2]);
-    float Le = p->env_strength * 4.01f, pdf = 1.0f;
+    float Le3[3] = {p->env_strength * 4.01f, p->env_strength * 4.01f, p->env_strength * 4.01f}, pdf = 1.0f;
+    if (p->use_env > 0 && k->env) {
+      float wi[3], lp[4];
+      vxo_env_sample(k->env, p->env_strength, e0, e1, wi, lp);
+      w_i = V3(wi[0], wi[1], wi[2]);
+      Le3[0] = lp[0]; Le3[1] = lp[1]; Le3[2] = lp[2]; pdf = lp[3];
+    }
     if (pdf > 0.0f) {
       f_p = phase_hg(dot3(neg3(ray.d), w_i), p->volume_phase_g);
       float mis = p->show_environment > 0 ? power_heuristic(pdf, f_p) : 1.0f;
       Ray sr = {ray.o, w_i};
       float Tr = transmittance(k, sr, s);
       /* :97 L += throughput * mis_weight * f_p * Tr * Le_pdf.rgb / Le_pdf.w */
-      L.x += thr.x * mis * f_p * Tr * Le / pdf;
-      L.y += thr.y * mis * f_p * Tr * Le / pdf;
-      L.z += thr.z * mis * f_p * Tr * Le / pdf;
+      L.x += thr.x * mis * f_p * Tr * Le3[0] / pdf;
+      L.y += thr.y * mis * f_p * Tr * Le3[1] / pdf;
+      L.z += thr.z * mis * f_p * Tr * Le3[2] / pdf;
     }
     if (++n_paths >= (uint32_t)p->bounces) { free_path = 0; break; } /* :101 */
     float rr = luma(thr); /* :103-108 */
@@ -1111,10 +1242,17 @@ static void shade_pixel(Ctx* k, int32_t px, int32_t py, float result[4], Ray* ra
 int vxo_render(const VxParams* p, uint32_t frame_index, float sample_weight, const VxoVolume* v,
                const float* tf, uint32_t tf_len, const float* prev, float* out, int32_t x0,
                int32_t x1, int32_t y0, int32_t y1, VxoCounters* counters) {
+  return vxo_render_env(p, frame_index, sample_weight, v, tf, tf_len, NULL, prev, out, x0, x1, y0, y1, counters);
+}
+
+int vxo_render_env(const VxParams* p, uint32_t frame_index, float sample_weight, const VxoVolume* v,
+                   const float* tf, uint32_t tf_len, const VxoEnvironment* env, const float* prev,
+                   float* out, int32_t x0, int32_t x1, int32_t y0, int32_t y1, VxoCounters* counters) {
   if (!p || !v || !tf || !out || tf_len == 0) return 1;
+  if (p->use_env > 0 && !env) return 2;
   Ctx k;
   memset(&k, 0, sizeof k);
-  k.p = p; k.v = v; k.tf = tf; k.tf_len = tf_len; k.frame = frame_index;
+  k.p = p; k.v = v; k.tf = tf; k.tf_len = tf_len; k.frame = frame_index; k.env = env;
   uint32_t* mask = NULL;
   if (p->dvr_skip_empty && (p->render_mode == VX_MODE_DVR || p->render_mode == VX_MODE_DVR_PHONG) &&
       !p->debug_hits) {

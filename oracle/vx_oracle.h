@@ -80,6 +80,36 @@ float vxo_lookup_majorant(const VxoVolume* v, float density_scale, float px, flo
 void vxo_lookup_transfer(const float* tf, uint32_t tf_len, const float sample_range[2], float d,
                          float out[4]);
 
+/* ---- environment map + importance map (representation/environment.ts, shaders/envSetup.frag,
+ *      shaders/environment.glsl).  texture = RGBA32F texels in GL orientation (row 0 = bottom, i.e.
+ *      after UNPACK_FLIP_Y_WEBGL, environment.ts:30-32); importance = mip pyramid of the 512x512 R32F
+ *      map, level k at offset vxo_imp_offset(k), (512>>k)^2 floats, level 9 = 1 texel.
+ *      [build] texture(): LINEAR on level 0 (MAX_LEVEL 0), REPEAT in s, CLAMP_TO_EDGE in t, weights
+ *      are the exact fp32 fractions (GL leaves the weight precision to the implementation);
+ *      generateMipmap = 2x2 box, ((a+b)+c+d)*0.25. */
+#define VXO_IMP_DIM 512u
+#define VXO_IMP_LEVELS 10u
+#define VXO_IMP_FLOATS 349525u
+typedef struct VxoEnvironment {
+  const float* texture; /* width*height*4 */
+  uint32_t width, height;
+  const float* importance; /* VXO_IMP_FLOATS */
+} VxoEnvironment;
+uint32_t vxo_imp_offset(uint32_t level);
+void vxo_env_flip_rows(const float* top_first, uint32_t w, uint32_t h, float* gl_rows);
+void vxo_env_texture(const VxoEnvironment* e, float u, float v, float rgb[3]);
+void vxo_env_build_importance(const float* texture, uint32_t w, uint32_t h, float* pyramid);
+/* environment.glsl:35-79 / :19-27 / :82-86 with u_use_env = 1 (env_strength applied) */
+void vxo_env_sample(const VxoEnvironment* e, float env_strength, float u0, float u1, float w_i[3],
+                    float le_pdf[4]);
+void vxo_env_lookup(const VxoEnvironment* e, float env_strength, const float dir[3], float rgb[3]);
+float vxo_env_pdf(const VxoEnvironment* e, float env_strength, const float dir[3]);
+
+/* vxo_render with an environment (params.use_env = 1 needs one; NULL = directional light only) */
+int vxo_render_env(const VxParams* p, uint32_t frame_index, float sample_weight, const VxoVolume* v,
+                   const float* tf, uint32_t tf_len, const VxoEnvironment* env, const float* prev,
+                   float* out, int32_t x0, int32_t x1, int32_t y0, int32_t y1, VxoCounters* counters);
+
 /* ---- full fragment program (shaders/fragment.frag main) over a pixel rectangle ----
  * out / prev: res.x*res.y*4 floats, row 0 = bottom.  Only pixels in [x0,x1) x [y0,y1) are
  * written.  prev may be NULL when sample_weight == 0. */

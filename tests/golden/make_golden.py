@@ -29,7 +29,14 @@ CASES = {
     "noise32_no_dda": ("noise", 32, (32, 32), "no_dda", dict(bench=True, frame=1)),
     "noise32_default": ("noise", 32, (32, 32), "default", dict(bench=True, frame=4)),
     "noise32_default_b3": ("noise", 32, (24, 24), "default", dict(bench=True, frame=6, bounces=3)),
+    # with the viewer's default environment map resident (use_env = 1, environment.ts:102-130)
+    "sphere32_debughits_env": ("sphere", 32, (40, 32), "dvr", dict(debug_hits=True, env=True, cam_pos=(0.3, -1.5, -2.0))),
+    "noise32_dvr_env": ("noise", 32, (48, 40), "dvr", dict(bench=True, env=True)),
+    "noise32_raymarch_env": ("noise", 32, (32, 32), "raymarch", dict(bench=True, frame=2, env=True)),
+    "noise32_no_dda_env": ("noise", 32, (32, 32), "no_dda", dict(bench=True, frame=1, env=True)),
+    "noise32_default_b3_env": ("noise", 32, (24, 24), "default", dict(bench=True, frame=6, bounces=3, env=True)),
 }
+ENV_CASES = [n for n, c in CASES.items() if c[4].get("env")]
 
 
 def build_case(oracle, name):
@@ -57,8 +64,30 @@ def build_case(oracle, name):
 
 
 def render_case(oracle, name):
+    from tests.common import default_environment
     grid, tf, L, p, frame = build_case(oracle, name)
-    return oracle.render(p, grid, tf, L, frame_index=frame, threads=1)
+    env = default_environment(oracle) if p.use_env else None
+    return oracle.render(p, grid, tf, L, frame_index=frame, threads=1, env=env)
+
+
+ENV_KAT_U = [(0.0, 0.0), (0.5, 0.5), (0.25, 0.75), (0.999999, 0.000001), (0.6369617, 0.26978672),
+             (0.04097353, 0.01652764), (0.8132702, 0.91275555), (0.123, 0.987)]
+
+
+def env_fixture(oracle):
+    """importance pyramid (levels 4..9 whole, levels 0..3 as float64 sums) and sample/lookup/pdf
+    known answers of the default environment"""
+    from tests.common import default_environment
+    e = default_environment(oracle)
+    out = {"tail": np.concatenate([e.level(k).ravel() for k in range(4, 10)]),
+           "sums": np.array([e.level(k).astype(np.float64).sum() for k in range(4)]),
+           "u": np.array(ENV_KAT_U, dtype=np.float32)}
+    wi, lp, look, pdf = [], [], [], []
+    for u0, u1 in out["u"]:
+        a, b = e.sample(float(u0), float(u1), 1.5)
+        wi.append(a); lp.append(b); look.append(e.lookup(a, 1.5)); pdf.append(e.pdf(a, 1.5))
+    out.update(w_i=np.array(wi), le_pdf=np.array(lp), lookup=np.array(look), pdf=np.array(pdf, dtype=np.float32))
+    return out
 
 
 def main():
@@ -69,6 +98,7 @@ def main():
         np.savez_compressed(os.path.join(HERE, name + ".npz"), image=img, samples=np.uint64(c.samples),
                             rays=np.uint64(c.rays))
         print(name, img.shape, "samples", c.samples, "max", float(img[..., :3].max()))
+    np.savez_compressed(os.path.join(HERE, "env_default.npz"), **env_fixture(O))
     L = O.lib()
     kat = {"tea": [], "wang": [], "xoshiro": []}
     for v0, v1 in [(0, 0), (1, 0), (0, 1), (42 * 12345, 17), (0xFFFFFFFF, 0xFFFFFFFF)]:

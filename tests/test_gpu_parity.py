@@ -112,6 +112,91 @@ def test_golden_stochastic_modes(oracle, name, layout):
     assert c.rays == int(want["rays"])
 
 
+# ---- row N3: environment-map lighting (environment.ts, envSetup.frag, environment.glsl) ----------
+def test_importance_pyramid_is_bit_identical(oracle):
+    """vx_upload_environment builds the 512^2 importance map + mips on the device: same bits as the
+    oracle for the default checkerboard and for a random HDR-like map"""
+    from volxel_amd import Environment, Volxel3DRenderer
+    r = Volxel3DRenderer(64, 64)
+    rng = np.random.default_rng(11)
+    hdr = np.exp(rng.normal(0, 1.5, size=(37, 64, 4))).astype(np.float32)
+    for env in (Environment.default(), Environment(hdr, 64, 37)):
+        r.set_environment(env)
+        got = np.zeros(oracle.IMP_FLOATS, dtype=np.float32)
+        r._check(r._lib.vx_debug_read_importance(r._ctx, got.ctypes.data))
+        want = oracle.Environment(env.floats, env.width, env.height).importance
+        assert np.array_equal(got, want)
+    r.set_environment(None)
+    assert r._lib.vx_debug_read_importance(r._ctx, got.ctypes.data) != 0
+
+
+@pytest.mark.parametrize("name", ["sphere32_debughits_env", "noise32_dvr_env"])
+def test_golden_environment_deterministic(oracle, name):
+    """background through lookup_environment's map branch; atan/acos come from two math libraries,
+    which moves the bilinear weights by ~1e-7 * width: tolerance 1e-5 (2e-6 without a map)"""
+    from tests.golden.make_golden import build_case
+    grid, tf, L, p, frame = build_case(oracle, name)
+    assert p.use_env == 1
+    want = np.load(os.path.join(GOLD, name + ".npz"))
+    for layout in (0, 1, 2):
+        r = _renderer(grid, tf, L, p, layout)
+        r.reset_counters()
+        img = _render_with_params(r, p, frame)
+        c = r.counters()
+        assert np.abs(img - want["image"]).max() <= 1e-5, (name, layout)
+        assert c.samples == int(want["samples"]) and c.rays == int(want["rays"])
+
+
+@pytest.mark.parametrize("name", ["noise32_raymarch_env", "noise32_no_dda_env", "noise32_default_b3_env"])
+def test_golden_environment_stochastic_modes(oracle, name):
+    """light sampling by the hierarchical warp, MIS against pdf_environment, escaped paths"""
+    from tests.golden.make_golden import build_case
+    grid, tf, L, p, frame = build_case(oracle, name)
+    assert p.use_env == 1
+    want = np.load(os.path.join(GOLD, name + ".npz"))
+    r = _renderer(grid, tf, L, p, 1)
+    r.reset_counters()
+    img = _render_with_params(r, p, frame)
+    c = r.counters()
+    diff = np.abs(img - want["image"]).max(axis=2)
+    frac = (diff <= 1e-4).mean()
+    assert frac >= 0.995, (name, frac, diff.max())
+    assert abs(int(c.samples) - int(want["samples"])) <= 0.005 * int(want["samples"]) + 64
+    assert c.rays == int(want["rays"])
+
+
+def test_environment_custom_map_and_errors(oracle):
+    """a non-default map, strength from the settings, use_env without a map is refused"""
+    from tests.common import make_scene, benchmark_tf, BENCH_CAM
+    from volxel_amd import Environment, synth
+    vox, sp = synth.value_noise(32, seed=5, zero_quantile=0.4)
+    g = oracle.BrickGrid(vox, sp)
+    tf, L = benchmark_tf()
+    rng = np.random.default_rng(5)
+    hdr = np.exp(rng.normal(0, 1.0, size=(16, 32, 4))).astype(np.float32)
+    env = Environment(hdr, 32, 16, strength=0.7)
+    r = _renderer(g, tf, L, make_scene(g, 48, 40)[4], 1)
+    r.set_environment(env)
+    r.settings.render_mode = "raymarch"
+    r.settings.bounces = 2
+    r.settings.sample_range = (0.05, 1.0)
+    r.camera.pos = np.asarray(BENCH_CAM["cam_pos"], dtype=np.float64)
+    r.camera.view = np.asarray(BENCH_CAM["look_at"], dtype=np.float64)
+    r.render(3)                                   # frames 0..2, weight 0: the last one stays
+    p = r._params
+    assert p.use_env == 1 and abs(p.env_strength - 0.7) < 1e-7
+    oenv = oracle.Environment(env.floats, env.width, env.height)
+    want, oc = oracle.render(p, g, tf, L, frame_index=2, env=oenv)
+    diff = np.abs(r.read_accum() - want).max(axis=2)
+    assert (diff <= 1e-4).mean() >= 0.995, diff.max()
+    r.set_environment(None)
+    assert r.bind_uniforms().use_env == 0          # host falls back to the directional light
+    p.use_env = 1
+    r._check(r._lib.vx_set_params(r._ctx, C.byref(p)))
+    assert r._lib.vx_render_frame(r._ctx, 0, 0.0) != 0
+    assert b"vx_upload_environment" in r._lib.vx_last_error(r._ctx)
+
+
 def test_config1_sphere_256_live_oracle(oracle):
     """BASELINE config 1: 64^3 sphere, 256x256, default white ramp, reference perspective camera"""
     from tests.common import make_scene
@@ -170,6 +255,7 @@ def test_progressive_accumulation_matches_oracle(oracle):
         prev = want
     # the host-level render() loop does the same thing
     r2 = _renderer(g, tf, L, p, 1)
+    r2.set_environment(None)           # p was built without a map: directional light
     r2.settings = s
     r2.camera = cam
     r2.render(frames=8)
@@ -259,8 +345,10 @@ def test_low_resolution_preview_ramp(oracle):
     assert (r.width, r.height) == (lw, lh) == (25, 16)
     r.render(3)
     assert r.frame_index == 3 and (r.width, r.height) == (lw, lh)
-    p = compute_params(r.settings, r.camera, r.volume, r.density_scale, lw, lh)
-    want, _ = oracle.render(p, g, tf, L, frame_index=2, sample_weight=0.0)
+    env = oracle.Environment(r.environment.floats, r.environment.width, r.environment.height)
+    p = compute_params(r.settings, r.camera, r.volume, r.density_scale, lw, lh, has_environment=True)
+    assert p.use_env == 1                          # the viewer's default: checkerboard map, useEnv
+    want, _ = oracle.render(p, g, tf, L, frame_index=2, sample_weight=0.0, env=env)
     low = r.read_accum()
     assert low.shape == (lh, lw, 4) and np.abs(low - want).max() <= 4e-6
     disp = r.read_display()
@@ -272,16 +360,16 @@ def test_low_resolution_preview_ramp(oracle):
     r.render(4, in_flight=4)                       # frames 3,4 low; 5,6 at full size
     fw, fh = math.floor(96 * 0.8), math.floor(64 * 0.8)
     assert r.frame_index == 7 and (r.width, r.height) == (fw, fh) and r.resolution_factor == 1.0
-    p = compute_params(r.settings, r.camera, r.volume, r.density_scale, fw, fh)
+    p = compute_params(r.settings, r.camera, r.volume, r.density_scale, fw, fh, has_environment=True)
     prev = None
     for f in (5, 6):
-        prev, _ = oracle.render(p, g, tf, L, frame_index=f, sample_weight=sample_weight(f), prev=prev)
+        prev, _ = oracle.render(p, g, tf, L, frame_index=f, sample_weight=sample_weight(f), prev=prev, env=env)
     assert np.abs(r.read_accum() - prev).max() <= 4e-6
     r.restart_rendering()                          # any restart drops back to the preview size
     assert (r.width, r.height, r.frame_index) == (lw, lh, 0)
     r.render(1)
-    want, _ = oracle.render(compute_params(r.settings, r.camera, r.volume, r.density_scale, lw, lh), g, tf, L,
-                            frame_index=0, sample_weight=0.0)
+    want, _ = oracle.render(compute_params(r.settings, r.camera, r.volume, r.density_scale, lw, lh,
+                                           has_environment=True), g, tf, L, frame_index=0, sample_weight=0.0, env=env)
     assert np.abs(r.read_accum() - want).max() <= 4e-6
 
 
@@ -316,12 +404,13 @@ def test_benchmark_runner_records(oracle):
     r2.restore_settings(shared)
     r2.render_mode = "dvr"
     r2.render(8)
-    p = compute_params(r2.settings, r2.camera, r2.volume, r2.density_scale, fw, fh)
+    p = compute_params(r2.settings, r2.camera, r2.volume, r2.density_scale, fw, fh, has_environment=True)
+    env = oracle.Environment(r2.environment.floats, r2.environment.width, r2.environment.height)
     from tests.common import benchmark_tf
     tf, L = benchmark_tf()
     prev = None
     for f in (5, 6, 7):
-        prev, _ = oracle.render(p, g, tf, L, frame_index=f, sample_weight=sample_weight(f), prev=prev)
+        prev, _ = oracle.render(p, g, tf, L, frame_index=f, sample_weight=sample_weight(f), prev=prev, env=env)
     assert (r2.width, r2.height) == (fw, fh)
     assert np.abs(r2.read_accum() - prev).max() <= 4e-6
 

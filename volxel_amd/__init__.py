@@ -10,3 +10,4 @@ from .settings import (ViewerSettings, BENCHMARK_SETTINGS, BENCHMARK_COLLECTION_
                        verify_benchmark, load_settings)
 from .scene import Camera, Volume, Grid  # noqa: F401
 from .preprocessor import read_u16_stack_to_grid, read_dicoms_to_grid, BrickGridMessage  # noqa: F401
+from .environment import Environment  # noqa: F401,E402

@@ -60,6 +60,9 @@ struct VxContext {
   float4* slab = nullptr;
   size_t slab_quads = 0;
   float4* image = nullptr;
+  float4* env_tex = nullptr;   // environment map, GL row order
+  float* env_imp = nullptr;    // importance pyramid
+  uint32_t env_w = 0, env_h = 0;
   uchar4* display = nullptr;
   uint32_t display_cap = 0;  // pixels
   size_t slab_cap = 0, image_cap = 0;
@@ -406,6 +409,8 @@ void vx_destroy(VxContext* c) {
   }
   free_volume(c);
   if (c->tf) (void)hipFree(c->tf);
+  if (c->env_tex) (void)hipFree(c->env_tex);
+  if (c->env_imp) (void)hipFree(c->env_imp);
   if (c->skip_dev) (void)hipFree(c->skip_dev);
   if (c->slab) (void)hipFree(c->slab);
   if (c->image) (void)hipFree(c->image);
@@ -569,14 +574,54 @@ int vx_upload_transfer(VxContext* c, const float* rgba, uint32_t length) {
   return VX_OK;
 }
 
+int vx_upload_environment(VxContext* c, const float* rgba, uint32_t w, uint32_t h) {
+  if (!c) return VX_ERR_INVALID;
+  VX_HIP(c, hipSetDevice(c->device));
+  VX_HIP(c, hipStreamSynchronize(c->stream));
+  for (auto& p : c->pipes)
+    if (p.stream) VX_HIP(c, hipStreamSynchronize(p.stream));
+  if (c->env_tex) (void)hipFree(c->env_tex);
+  if (c->env_imp) (void)hipFree(c->env_imp);
+  c->env_tex = nullptr;
+  c->env_imp = nullptr;
+  c->env_w = c->env_h = 0;
+  if (!rgba) return VX_OK;
+  if (w == 0 || h == 0 || w > 16384 || h > 16384)
+    VX_FAIL(c, VX_ERR_INVALID, "vx_upload_environment: bad size %ux%u", w, h);
+  std::vector<float> flipped((size_t)w * h * 4);  // UNPACK_FLIP_Y_WEBGL, environment.ts:30-32
+  for (uint32_t y = 0; y < h; ++y)
+    memcpy(flipped.data() + (size_t)(h - 1 - y) * w * 4, rgba + (size_t)y * w * 4, (size_t)w * 16);
+  VX_HIP(c, hipMalloc(&c->env_tex, flipped.size() * sizeof(float)));
+  VX_HIP(c, hipMalloc(&c->env_imp, (size_t)IMP_FLOATS * sizeof(float)));
+  VX_HIP(c, hipMemcpy(c->env_tex, flipped.data(), flipped.size() * sizeof(float), hipMemcpyHostToDevice));
+  c->env_w = w;
+  c->env_h = h;
+  hipLaunchKernelGGL(build_importance, dim3(IMP_DIM * IMP_DIM / 256), dim3(256), 0, c->stream, c->env_tex, w, h,
+                     c->env_imp);
+  for (uint32_t k = 1; k < IMP_LEVELS; ++k) {
+    uint32_t n = (IMP_DIM >> k) * (IMP_DIM >> k);
+    hipLaunchKernelGGL(build_importance_mip, dim3((n + 255) / 256), dim3(256), 0, c->stream, c->env_imp, k);
+  }
+  VX_HIP(c, hipGetLastError());
+  VX_HIP(c, hipStreamSynchronize(c->stream));
+  return VX_OK;
+}
+
+int vx_debug_read_importance(VxContext* c, float* out) {
+  if (!c || !out) return VX_ERR_INVALID;
+  if (!c->env_imp) VX_FAIL(c, VX_ERR_INVALID, "vx_debug_read_importance: no environment uploaded");
+  VX_HIP(c, hipStreamSynchronize(c->stream));
+  VX_HIP(c, hipMemcpy(out, c->env_imp, (size_t)IMP_FLOATS * sizeof(float), hipMemcpyDeviceToHost));
+  return VX_OK;
+}
+
 int vx_set_params(VxContext* c, const VxParams* p) {
   if (!c || !p) return VX_ERR_INVALID;
   if (p->render_mode < VX_MODE_DEFAULT || p->render_mode > VX_MODE_DVR_PHONG)
     VX_FAIL(c, VX_ERR_INVALID, "vx_set_params: unknown render mode %d", p->render_mode);
   if (p->shard_count < 1 || p->shard_rank < 0 || p->shard_rank >= p->shard_count)
     VX_FAIL(c, VX_ERR_INVALID, "vx_set_params: bad shard %d/%d", p->shard_rank, p->shard_count);
-  if (p->use_env != 0)
-    VX_FAIL(c, VX_ERR_INVALID, "vx_set_params: environment-map lighting is not implemented (use_env must be 0)");
+  if (p->use_env != 0 && p->use_env != 1) VX_FAIL(c, VX_ERR_INVALID, "vx_set_params: use_env must be 0 or 1");
   if (c->W && ((uint32_t)p->res[0] != c->W || (uint32_t)p->res[1] != c->H))
     VX_FAIL(c, VX_ERR_INVALID, "vx_set_params: res %dx%d differs from vx_resize %ux%u", p->res[0],
             p->res[1], c->W, c->H);
@@ -612,6 +657,12 @@ static int prepare_render(VxContext* c, dim3& grid) {
   if (!c->slab) VX_FAIL(c, VX_ERR_INVALID, "vx_render_frame: vx_resize not called");
   if ((uint32_t)c->params.res[0] != c->W || (uint32_t)c->params.res[1] != c->H)
     VX_FAIL(c, VX_ERR_INVALID, "vx_render_frame: params.res differs from the framebuffer size");
+  if (c->params.use_env > 0 && !c->env_tex)
+    VX_FAIL(c, VX_ERR_INVALID, "vx_render_frame: use_env = 1 without vx_upload_environment");
+  c->dv.env_tex = c->env_tex;
+  c->dv.env_imp = c->env_imp;
+  c->dv.env_w = c->env_w;
+  c->dv.env_h = c->env_h;
   {
     const VxParams& p = c->params;
     bool dvr = p.render_mode == VX_MODE_DVR || p.render_mode == VX_MODE_DVR_PHONG;

@@ -39,7 +39,18 @@ struct DevVolume {
   uint32_t skip_level;
   uint32_t skip_dims[3];        // (extent >> (3 + level)) + 1
   uint32_t skip_words;
+  // environment map (environment.ts): RGBA32F texels in GL row order + importance mip pyramid
+  const float4* env_tex;        // nullptr: none (directional light only)
+  uint32_t env_w, env_h;
+  const float* env_imp;         // levels 0..9 of the 512^2 map back to back (imp_offset)
 };
+
+constexpr uint32_t IMP_DIM = 512, IMP_LEVELS = 10, IMP_FLOATS = 349525;
+VXD constexpr uint32_t imp_offset(uint32_t level) {
+  uint32_t o = 0;
+  for (uint32_t k = 0; k < level; ++k) o += (IMP_DIM >> k) * (IMP_DIM >> k);
+  return o;
+}
 
 // macro cell of trilinear cell c (given as c+1 >= 0): is it flagged empty?
 VXD bool skip_test(const uint32_t* bits, uint32_t sh, uint32_t d0, uint32_t d1, uint32_t cx, uint32_t cy,
@@ -349,12 +360,83 @@ VXD void to_index(const VxParams& p, const Ray& r, V3& ipos, V3& idir) {
   idir = v3(b[0], b[1], b[2]);
 }
 
-// environment.glsl:19-22 directional branch; pow base clamped at 0 ([build], quirk Q16)
-VXD float lookup_environment(const VxParams& p, V3 dir) {
+// texture(u_envmap, uv): LINEAR on level 0, REPEAT in s, CLAMP_TO_EDGE in t (environment.ts:22-26);
+// [build] exact fp32 fractions as weights
+VXD V3 env_texture(const float4* __restrict__ tex, uint32_t w, uint32_t h, float u, float v) {
+  float x = fma_(u, (float)w, -0.5f), y = fma_(v, (float)h, -0.5f);
+  float fx = floorf(x), fy = floorf(y);
+  float a = x - fx, b = y - fy;
+  int W = (int)w, H = (int)h;
+  int i0 = f2i(fx), j0 = f2i(fy);
+  int i1 = i0 + 1, j1 = j0 + 1;
+  i0 %= W; if (i0 < 0) i0 += W;
+  i1 %= W; if (i1 < 0) i1 += W;
+  j0 = j0 < 0 ? 0 : (j0 > H - 1 ? H - 1 : j0);
+  j1 = j1 < 0 ? 0 : (j1 > H - 1 ? H - 1 : j1);
+  float4 t00 = tex[(size_t)j0 * w + i0], t10 = tex[(size_t)j0 * w + i1];
+  float4 t01 = tex[(size_t)j1 * w + i0], t11 = tex[(size_t)j1 * w + i1];
+  float na = 1.0f - a, nb = 1.0f - b;
+  V3 lo = v3(fma_(t10.x, a, t00.x * na), fma_(t10.y, a, t00.y * na), fma_(t10.z, a, t00.z * na));
+  V3 hi = v3(fma_(t11.x, a, t01.x * na), fma_(t11.y, a, t01.y * na), fma_(t11.z, a, t01.z * na));
+  return v3(fma_(hi.x, b, lo.x * nb), fma_(hi.y, b, lo.y * nb), fma_(hi.z, b, lo.z * nb));
+}
+VXD float env_luma(V3 col) { return dot3(col, v3(0.212671f, 0.715160f, 0.072169f)); }
+VXD float imp_fetch(const float* __restrict__ imp, int x, int y, int mip) {
+  int n = (int)(IMP_DIM >> mip);
+  if (x < 0 || y < 0 || x >= n || y >= n) return 0.0f;
+  return imp[imp_offset((uint32_t)mip) + (size_t)y * n + x];
+}
+
+// environment.glsl:19-27; directional branch: pow base clamped at 0 ([build], quirk Q16)
+VXD V3 lookup_environment(const VxParams& p, const DevVolume& dv, V3 dir) {
+  if (p.use_env > 0) {
+    const float pi = 3.14159265358979323846f;
+    float u = atan2f(dir.z, dir.x) / (2.0f * pi) + 0.5f;
+    float v = 1.0f - acosf(dir.y) / pi;
+    V3 t = env_texture(dv.env_tex, dv.env_w, dv.env_h, u, v);
+    return v3(p.env_strength * t.x, p.env_strength * t.y, p.env_strength * t.z);
+  }
   V3 nl = v3(-p.light_dir[0], -p.light_dir[1], -p.light_dir[2]);
   float c = gl_max(dot3(dir, nl), 0.0f);
   float s = gl_clamp(powf(c, 300.0f), 0.0f, 1.0f);
-  return p.env_strength * fma_(s, 4.0f, 0.01f);
+  float e = p.env_strength * fma_(s, 4.0f, 0.01f);
+  return v3(e, e, e);
+}
+// environment.glsl:82-86 (u_use_env = 1 only)
+VXD float pdf_environment(const VxParams& p, const DevVolume& dv, V3 dir) {
+  const float inv_4pi = 1.0f / (4.0f * 3.14159265358979323846f);
+  V3 le = lookup_environment(p, dv, dir);
+  float avg_w = imp_fetch(dv.env_imp, 0, 0, (int)IMP_LEVELS - 1);
+  return env_luma(le) / avg_w * inv_4pi;
+}
+// environment.glsl:35-79 (u_use_env = 1 only): hierarchical warp over the importance mips
+VXD float4 sample_environment(const VxParams& p, const DevVolume& dv, float u0, float u1, V3& w_i) {
+  const float pi = 3.14159265358979323846f, inv_4pi = 1.0f / (4.0f * 3.14159265358979323846f);
+  int px = 0, py = 0;
+  float sx = u0, sy = u1;
+  for (int mip = (int)IMP_LEVELS - 2; mip >= 0; --mip) {
+    px *= 2; py *= 2;
+    float w0 = imp_fetch(dv.env_imp, px, py, mip), w1 = imp_fetch(dv.env_imp, px + 1, py, mip);
+    float w2 = imp_fetch(dv.env_imp, px, py + 1, mip), w3 = imp_fetch(dv.env_imp, px + 1, py + 1, mip);
+    float q0 = w0 + w2, q1 = w1 + w3;
+    float d = q0 / gl_max(1e-8f, q0 + q1);
+    float wsel, qsel;
+    if (sx < d) { sx = sx / d; wsel = w0; qsel = q0; }
+    else { sx = (sx - d) / (1.0f - d); px += 1; wsel = w1; qsel = q1; }
+    float e = wsel / qsel;
+    if (sy < e) { sy = sy / e; }
+    else { py += 1; sy = (sy - e) / (1.0f - e); }
+  }
+  const float inv_dim = 1.0f / (float)IMP_DIM;
+  float uvx = ((float)px + sx) * inv_dim, uvy = ((float)py + sy) * inv_dim;
+  float theta = gl_clamp(1.0f - uvy, 0.0f, 1.0f) * pi;
+  float phi = (gl_clamp(uvx, 0.0f, 1.0f) * 2.0f - 1.0f) * pi;
+  float sin_t = sinf(theta);
+  w_i = v3(sin_t * cosf(phi), cosf(theta), sin_t * sinf(phi));
+  V3 t = env_texture(dv.env_tex, dv.env_w, dv.env_h, uvx, uvy);
+  float avg_w = imp_fetch(dv.env_imp, 0, 0, (int)IMP_LEVELS - 1);
+  float pdf = imp_fetch(dv.env_imp, px, py, 0) / avg_w;
+  return make_float4(p.env_strength * t.x, p.env_strength * t.y, p.env_strength * t.z, pdf * inv_4pi);
 }
 
 VXD float sanitize1(float x) { return (x != x || __builtin_isinf(x)) ? 0.0f : x; }

@@ -44,14 +44,14 @@ VXD DvrRay dvr_setup(const VxParams& p, int px, int py, uint32_t frame) {
 }
 
 // write-back shared by the tuned DVR kernels: gain, background, sanitize, running mean
-VXD void dvr_store(const VxParams& p, const DvrRay& r, float Cx, float Cy, float Cz, float T,
+VXD void dvr_store(const VxParams& p, const DevVolume& dv, const DvrRay& r, float Cx, float Cy, float Cz, float T,
                    float weight, float4* __restrict__ slab, uint32_t si) {
   float Lx = Cx * p.dvr_gain[0], Ly = Cy * p.dvr_gain[1], Lz = Cz * p.dvr_gain[2];
   if (p.show_environment > 0 && T > 0.0f) {
-    float env = lookup_environment(p, r.wdir);
-    Lx = fma_(T, env, Lx);
-    Ly = fma_(T, env, Ly);
-    Lz = fma_(T, env, Lz);
+    V3 env = lookup_environment(p, dv, r.wdir);
+    Lx = fma_(T, env.x, Lx);
+    Ly = fma_(T, env.y, Ly);
+    Lz = fma_(T, env.z, Lz);
   }
   Lx = sanitize1(Lx); Ly = sanitize1(Ly); Lz = sanitize1(Lz);
   float4 prev = make_float4(0.f, 0.f, 0.f, 0.f);
@@ -236,7 +236,7 @@ __global__ __launch_bounds__(256) void render_dvr_cq(const VxParams p, const Dev
     }
   }
 
-  if (in_image) dvr_store(p, r, Cx, Cy, Cz, T, weight, slab, si);
+  if (in_image) dvr_store(p, v, r, Cx, Cy, Cz, T, weight, slab, si);
   const uint32_t n_px = (uint32_t)__builtin_popcountll(__ballot(in_image));
   add_counts(dc, n_samples, n_rays, n_px, n_skipped, 0u, n_slots, blk);
 }
@@ -444,7 +444,7 @@ __global__ __launch_bounds__(256) void render_dvr_dp(const VxParams p, const Dev
   const bool writer = in_image && j == 7u;
   if (writer) {
     float T = (carry >= ert) ? 0.0f : __builtin_amdgcn_exp2f(carry * -1.4426950408889634f);
-    dvr_store(p, r, Cx, Cy, Cz, T, weight, slab, si);
+    dvr_store(p, v, r, Cx, Cy, Cz, T, weight, slab, si);
   }
   const uint32_t n_px = (uint32_t)__builtin_popcountll(__ballot(writer));
   add_counts(dc, n_samples, n_rays, n_px, n_skipped, 0u, n_slots);

@@ -239,7 +239,7 @@ __global__ __launch_bounds__(256) void render_dvr_tile(const VxParams p, const D
     }
   }
 
-  if (in_image) dvr_store(p, r, Cx, Cy, Cz, T, weight, slab, si);
+  if (in_image) dvr_store(p, v, r, Cx, Cy, Cz, T, weight, slab, si);
   const uint32_t n_px = (uint32_t)__builtin_popcountll(__ballot(in_image));
   add_counts(dc, n_samples, n_rays, n_px, n_direct, 0u, n_slots);
 }

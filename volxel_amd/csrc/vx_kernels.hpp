@@ -267,6 +267,35 @@ __global__ __launch_bounds__(256) void blit_rgba8(const float4* __restrict__ ima
   out[i] = make_uchar4(o[0], o[1], o[2], o[3]);
 }
 
+// envSetup.frag:26-41 over the 512x512 importance map, 8x8 bilinear taps per texel
+__global__ __launch_bounds__(256) void build_importance(const float4* __restrict__ tex, uint32_t w, uint32_t h,
+                                                         float* __restrict__ pyr) {
+  uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= IMP_DIM * IMP_DIM) return;
+  uint32_t px = i % IMP_DIM, py = i / IMP_DIM;
+  const int ns = 8;
+  const float out_size = (float)(IMP_DIM * ns), inv_samples = 1.0f / (float)(ns * ns);
+  float imp = 0.0f;
+  for (int y = 0; y < ns; ++y)
+    for (int x = 0; x < ns; ++x) {
+      float u = ((float)(px * ns) + ((float)x + 0.5f)) / out_size;
+      float v = ((float)(py * ns) + ((float)y + 0.5f)) / out_size;
+      imp += env_luma(env_texture(tex, w, h, u, v));
+    }
+  pyr[i] = imp * inv_samples;
+}
+// generateMipmap (environment.ts:58-60): 2x2 box, one level per launch
+__global__ __launch_bounds__(256) void build_importance_mip(float* __restrict__ pyr, uint32_t level) {
+  uint32_t n = IMP_DIM >> level, m = n * 2;
+  uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n * n) return;
+  uint32_t x = i % n, y = i / n;
+  const float* src = pyr + imp_offset(level - 1);
+  float a = src[(size_t)(2 * y) * m + 2 * x], b = src[(size_t)(2 * y) * m + 2 * x + 1];
+  float c = src[(size_t)(2 * y + 1) * m + 2 * x], d = src[(size_t)(2 * y + 1) * m + 2 * x + 1];
+  pyr[imp_offset(level) + i] = (((a + b) + c) + d) * 0.25f;
+}
+
 // test hook: the unorm8 table
 __global__ void unorm_table(float* out) { out[threadIdx.x] = unorm8(threadIdx.x); }
 

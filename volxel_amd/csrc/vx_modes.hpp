@@ -261,17 +261,19 @@ struct Frame {
     float t = 0.0f, f_p = 0.0f;
     while (sample_volume<MODE>(ray, t, thr, s)) {
       ray.o = madd3(ray.o, t, ray.d);
-      (void)rng(s);  // rng2 argument of sample_environment, fragment.frag:92
-      (void)rng(s);
+      float e0 = rng(s), e1 = rng(s);  // rng2 argument of sample_environment, fragment.frag:92
       V3 w_i = v3(-p.light_dir[0], -p.light_dir[1], -p.light_dir[2]);
-      float Le = p.env_strength * 4.01f;
-      const float pdf = 1.0f;
-      f_p = phase_hg(dot3(neg3(ray.d), w_i), p.volume_phase_g);
-      float mis = p.show_environment > 0 ? power_heuristic(pdf, f_p) : 1.0f;
-      float Tr = transmittance<MODE>(Ray{ray.o, w_i}, s);
-      L.x += thr.x * mis * f_p * Tr * Le / pdf;
-      L.y += thr.y * mis * f_p * Tr * Le / pdf;
-      L.z += thr.z * mis * f_p * Tr * Le / pdf;
+      float4 Le = make_float4(p.env_strength * 4.01f, p.env_strength * 4.01f, p.env_strength * 4.01f, 1.0f);
+      if (p.use_env > 0) Le = sample_environment(p, v, e0, e1, w_i);
+      const float pdf = Le.w;
+      if (pdf > 0.0f) {
+        f_p = phase_hg(dot3(neg3(ray.d), w_i), p.volume_phase_g);
+        float mis = p.show_environment > 0 ? power_heuristic(pdf, f_p) : 1.0f;
+        float Tr = transmittance<MODE>(Ray{ray.o, w_i}, s);
+        L.x += thr.x * mis * f_p * Tr * Le.x / pdf;
+        L.y += thr.y * mis * f_p * Tr * Le.y / pdf;
+        L.z += thr.z * mis * f_p * Tr * Le.z / pdf;
+      }
       if (++n_paths >= (uint32_t)p.bounces) { free_path = false; break; }
       float rr = luma(thr);
       if (rr < 0.1f) {
@@ -286,12 +288,13 @@ struct Frame {
       ray.d = sd;
     }
     if (free_path && p.show_environment > 0) {
-      float Le = lookup_environment(p, ray.d);
+      V3 Le = lookup_environment(p, v, ray.d);
       // pdf_environment is 0 for the delta light ([build]); power_heuristic(f_p, 0) = 1 or NaN(0/0)
-      float mis = n_paths > 0u ? power_heuristic(f_p, 0.0f) : 1.0f;
-      L.x = fma_(thr.x * mis, Le, L.x);
-      L.y = fma_(thr.y * mis, Le, L.y);
-      L.z = fma_(thr.z * mis, Le, L.z);
+      float pe = p.use_env > 0 ? pdf_environment(p, v, ray.d) : 0.0f;
+      float mis = n_paths > 0u ? power_heuristic(f_p, pe) : 1.0f;
+      L.x = fma_(thr.x * mis, Le.x, L.x);
+      L.y = fma_(thr.y * mis, Le.y, L.y);
+      L.z = fma_(thr.z * mis, Le.z, L.z);
     }
     return make_float4(L.x, L.y, L.z, gl_clamp((float)n_paths, 0.0f, 1.0f));
   }
@@ -362,10 +365,10 @@ struct Frame {
     }
     V3 L = v3(C.x * p.dvr_gain[0], C.y * p.dvr_gain[1], C.z * p.dvr_gain[2]);
     if (p.show_environment > 0 && T > 0.0f) {
-      float Le = lookup_environment(p, ray.d);
-      L.x = fma_(T, Le, L.x);
-      L.y = fma_(T, Le, L.y);
-      L.z = fma_(T, Le, L.z);
+      V3 Le = lookup_environment(p, v, ray.d);
+      L.x = fma_(T, Le.x, L.x);
+      L.y = fma_(T, Le.y, L.y);
+      L.z = fma_(T, Le.z, L.z);
     }
     return make_float4(L.x, L.y, L.z, hit ? 1.0f : 0.0f);
   }
@@ -391,8 +394,8 @@ struct Frame {
                         (h.z - p.volume_aabb_min[2]) / (p.volume_aabb_max[2] - p.volume_aabb_min[2]), 1.0f);
         c.rays++;
       } else {
-        float bg = lookup_environment(p, ray.d);
-        r = make_float4(bg, bg, bg, 1.0f);
+        V3 bg = lookup_environment(p, v, ray.d);
+        r = make_float4(bg.x, bg.y, bg.z, 1.0f);
       }
       return r;
     }

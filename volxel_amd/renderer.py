@@ -23,6 +23,7 @@ import numpy as np
 
 from . import _abi
 from .scene import Camera, Grid, Volume, flat, from_flat
+from .environment import Environment
 from .settings import ViewerSettings, verify_settings
 from .transfer import default_transfer_function, generate_transfer_function
 
@@ -42,7 +43,7 @@ def sample_weight(frame_index: int, low_res_duration: int = LOW_RESOLUTION_DURAT
 
 def compute_params(settings: ViewerSettings, camera: Camera, volume: Volume, density_scale: float,
                    width: int, height: int, env_strength: float = 1.0, shard_rank: int = 0,
-                   shard_count: int = 1) -> "_abi.VxParams":
+                   shard_count: int = 1, has_environment: bool = False) -> "_abi.VxParams":
     """bindUniforms (viewer.ts:1295-1357) + Camera.bindAsUniforms (scene.ts:53-56):
     doubles on the host, rounded to float32 on upload."""
     p = _abi.VxParams()
@@ -79,7 +80,8 @@ def compute_params(settings: ViewerSettings, camera: Camera, volume: Volume, den
     put("light_dir", settings.light_dir)                     # viewer.ts:1303
     p.env_strength = env_strength                            # environment.ts:83
     p.show_environment = 1 if settings.show_environment else 0   # viewer.ts:1338
-    p.use_env = 0   # env-map lighting is SURVEY row N3; the directional branch is implemented
+    # viewer.ts:1340; an environment map must be resident (the viewer always has the default one)
+    p.use_env = 1 if (settings.use_env and has_environment) else 0
     p.bounces = int(settings.bounces)                        # viewer.ts:1339
     p.res[0], p.res[1] = int(width), int(height)             # viewer.ts:1353 (quirk Q2 dropped)
     p.debug_hits = 1 if settings.debug_hits else 0           # viewer.ts:1354
@@ -125,7 +127,8 @@ class Volxel3DRenderer:
         self.camera = Camera(1)                       # viewer.ts:418
         self.volume: Volume | None = None
         self.density_scale = 1.0
-        self.env_strength = 1.0
+        self.environment: Environment | None = None
+        self._env_strength = 1.0
         self.frame_index = 0
         self.canvas_width, self.canvas_height = int(width), int(height)
         self.width, self.height = int(width), int(height)      # current render size
@@ -136,6 +139,7 @@ class Volxel3DRenderer:
         if layout is not None:
             self._check(self._lib.vx_set_layout(self._ctx, int(layout)))
         self._check(self._lib.vx_resize(self._ctx, self.width, self.height))
+        self.set_environment(Environment.default())   # viewer.ts:372-374
         data, length = default_transfer_function()    # viewer.ts:377-385
         self.change_transfer_func(data, length)
 
@@ -204,6 +208,26 @@ class Volxel3DRenderer:
         data, length = generate_transfer_function(colors, steps)
         self.change_transfer_func(data, length)
 
+    # -- viewer.ts:1073-1078 setupEnv --------------------------------------------------------
+    def set_environment(self, env: "Environment | None"):
+        """env = None removes the map: use_env then falls back to the directional light."""
+        if env is None:
+            self._check(self._lib.vx_upload_environment(self._ctx, None, 0, 0))
+        else:
+            self._check(self._lib.vx_upload_environment(self._ctx, env.floats.ctypes.data, env.width, env.height))
+        self.environment = env
+        self.restart_rendering()
+
+    @property
+    def env_strength(self) -> float:                  # environment.ts:15 `strength`
+        return self.environment.strength if self.environment is not None else self._env_strength
+
+    @env_strength.setter
+    def env_strength(self, v: float):
+        self._env_strength = float(v)
+        if self.environment is not None:
+            self.environment.strength = float(v)
+
     # -- viewer.ts:1155-1181 ------------------------------------------------------------
     def restart_rendering(self):
         if self.low_res_preview:                               # viewer.ts:1176-1178
@@ -220,6 +244,8 @@ class Volxel3DRenderer:
             self._check(self._lib.vx_resize(self._ctx, w, h))
 
     def resize(self, width: int, height: int):
+        if int(width) <= 0 or int(height) <= 0:
+            self._check(self._lib.vx_resize(self._ctx, max(0, int(width)), max(0, int(height))))  # raises
         self.canvas_width, self.canvas_height = int(width), int(height)
         self._resize_framebuffers_to_canvas()
         self.restart_rendering()
@@ -260,7 +286,8 @@ class Volxel3DRenderer:
         if self.volume is None:
             raise VolxelError("Trying to bind uniforms without a volume.")
         p = compute_params(self.settings, self.camera, self.volume, self.density_scale, self.width,
-                           self.height, self.env_strength, self.shard_rank, self.shard_count)
+                           self.height, self.env_strength, self.shard_rank, self.shard_count,
+                           has_environment=self.environment is not None)
         self._check(self._lib.vx_set_params(self._ctx, C.byref(p)))
         self._params = p
         return p
