@@ -75,7 +75,19 @@ def test_node_host_cpu(oracle, tmp_path):
 
 @pytest.mark.gpu
 def test_node_host_renders_like_the_oracle(oracle, tmp_path):
-    _run(tmp_path, "gpu")
+    import copy
+    from volxel_amd import BENCHMARK_SETTINGS
+    shared = copy.deepcopy(BENCHMARK_SETTINGS)
+    shared["display"]["samples"] = 6
+    coll = {"sharedSettings": [shared], "benchmarks": [{"renderMode": m, "settings": 0, "name": m}
+                                                      for m in ("default", "no_dda", "raymarch")]}
+    json.dump(coll, open(tmp_path / "bench.json", "w"))
+    _run(tmp_path, "gpu", str(tmp_path / "bench.json"))
+    res = json.load(open(tmp_path / "benchmark_results.json"))
+    assert [x["name"] for x in res] == ["default", "no_dda", "raymarch"]
+    for x in res:                                                     # frames 0..6
+        assert x["totalTime"] > 0 and abs(x["timePerSample"] - x["totalTime"] / 7) < 1e-9
+        assert x["viewport"] == [0, 0, 0.8 * 96, 0.8 * 64] and x["settings"]["renderMode"] == x["name"]
     g = _check_grid(oracle, tmp_path)
     p = oracle.VxParams()
     raw = open(tmp_path / "params.bin", "rb").read()
@@ -83,13 +95,15 @@ def test_node_host_renders_like_the_oracle(oracle, tmp_path):
     C.memmove(C.byref(p), raw, len(raw))
     from volxel_amd import default_transfer_function
     tf, L = default_transfer_function()
-    want, oc = oracle.render(p, g, tf, L)
+    from tests.common import default_environment
+    assert p.use_env == 1                         # the JS host uploads the default map like the viewer
+    want, oc = oracle.render(p, g, tf, L, env=default_environment(oracle))
     img = np.fromfile(tmp_path / "accum.bin", dtype=np.float32).reshape(p.res[1], p.res[0], 4)
-    assert np.abs(img - want).max() <= 2e-6
+    assert np.abs(img - want).max() <= 1e-5       # map background: atan/acos from two math libraries
     assert json.load(open(tmp_path / "counters.json"))["samples"] == oc.samples
     # the JS host's uniforms agree with the Python host's (both restate viewer.ts:1295-1357)
     from tests.common import make_scene
-    s, cam, vol, ds, pp = make_scene(g, p.res[0], p.res[1], "dvr")
+    s, cam, vol, ds, pp = make_scene(g, p.res[0], p.res[1], "dvr", env=True)
     a = np.frombuffer(raw, dtype=np.float32)
     b = np.frombuffer(bytes(pp), dtype=np.float32)
     assert np.allclose(a[:140], b[:140], rtol=1e-6, atol=1e-7)

@@ -11,8 +11,15 @@ export type BrickGridMessage = {            // WasmWorkerMessageDicomReturn, com
 export declare const VolxelRenderMode: { default: 0; no_dda: 1; raymarch: 2; dvr: 3; dvr_phong: 4 };
 export declare function generateTransferFunction(colors: ColorStop[], generatedSteps?: number): { data: Float32Array; length: number };
 export declare class Camera { pos: number[]; view: number[]; constructor(distance?: number); viewMatrix(): number[]; projMatrix(aspect: number, fov?: number): number[]; }
+export declare class Environment {          // representation/environment.ts; row 0 of `floats` = top
+  constructor(floats: Float32Array, width: number, height: number, strength?: number);
+  floats: Float32Array; width: number; height: number; strength: number;
+  static default(): Environment;
+}
 export declare class Volxel3DDicomRenderer {
-  constructor(opts?: { width?: number; height?: number; device?: number; layout?: number });
+  constructor(opts?: { width?: number; height?: number; device?: number; layout?: number; lowResPreview?: boolean });
+  environment: Environment | null;
+  setEnvironment(env: Environment | null): void;
   settings: Record<string, any>; camera: Camera; envStrength: number; frameIndex: number;
   renderMode: keyof typeof VolxelRenderMode;
   /** restartFromFiles (viewer.ts:833-866) for slices already read into memory */
@@ -22,6 +29,8 @@ export declare class Volxel3DDicomRenderer {
   changeTransferFunc(data: Float32Array, length: number): void;
   restartRendering(): void;
   restoreSettings(settings: any): void;
+  /** data-benchmark-url runner (viewer.ts:856-890); returns VolxelBenchmarkResult records */
+  startBenchmark(collection: { sharedSettings: any[]; benchmarks: any[] }, volumes?: Record<string, BrickGridMessage>): any[];
   bindUniforms(): { buffer: ArrayBuffer };
   render(frames?: number): void;
   finish(): void;

@@ -38,6 +38,10 @@ if (process.argv[3] === 'gpu') {
   fs.writeFileSync(path.join(out, 'accum.bin'), Buffer.from(r.readAccum().buffer));
   fs.writeFileSync(path.join(out, 'params.bin'), Buffer.from(r.params.buffer));
   fs.writeFileSync(path.join(out, 'counters.json'), JSON.stringify(r.counters()));
+  if (process.argv[4]) { // benchmark collection JSON -> result records (viewer.ts:856-890)
+    const coll = JSON.parse(fs.readFileSync(process.argv[4], 'utf8'));
+    fs.writeFileSync(path.join(out, 'benchmark_results.json'), JSON.stringify(r.startBenchmark(coll)));
+  }
   r.dispose();
 } else {
   let threw = false;

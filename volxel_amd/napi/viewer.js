@@ -127,6 +127,25 @@ class Camera { // representation/scene.ts
   projMatrix(aspect, fov = Math.PI / 3) { return M.perspective(fov, aspect, 0.1, 1000); }
 }
 
+/** representation/environment.ts: base map = width x height RGBA floats, row 0 = TOP */
+class Environment {
+  constructor(floats, width, height, strength = 1) {
+    if (floats.length !== width * height * 4) throw new Error('Environment: floats must hold width*height RGBA texels');
+    this.floats = floats; this.width = width; this.height = height; this.strength = strength;
+  }
+  static default() { // environment.ts:102-130, 8x6 checkerboard with a bright upper third
+    const width = 8, height = 6, d = new Float32Array(width * height * 4);
+    for (let y = 0; y < height; ++y) {
+      const top = y < Math.floor(height / 3);
+      for (let x = 0; x < width; ++x) {
+        const light = ((x + y) & 1) === 0, val = top ? (light ? 3 : 0.9) : (light ? 0.1 : 0.0), i = (y * width + x) * 4;
+        d[i] = d[i + 1] = d[i + 2] = val; d[i + 3] = 1;
+      }
+    }
+    return new Environment(d, width, height);
+  }
+}
+
 class Volxel3DDicomRenderer {
   /** width, height: the canvas.  lowResPreview reproduces the viewer's interactive sizing
    *  (settings.resolutionFactor and the 0.33 ramp of viewer.ts:1167-1188); off = full-size frames. */
@@ -142,15 +161,24 @@ class Volxel3DDicomRenderer {
       dvrStepVoxels: 0.5, dvrErtEpsilon: 1e-4, dvrJitter: false, dvrMaxSteps: 1 << 20, dvrSkipEmpty: true, phong: [0.3, 0.7, 0.4, 32],
     };
     this.camera = new Camera(1);                  // viewer.ts:418
-    this.envStrength = 1;
+    this.environment = null;
     this.frameIndex = 0;
     this.densityScale = 1;
     this.volume = null;
     if (layout !== undefined) native.setLayout(this.ctx, layout);
     native.resize(this.ctx, width, height);
+    this.setEnvironment(Environment.default());   // viewer.ts:372-374
     const tf = generateTransferFunction([{ color: [1, 1, 1, 0], stop: 0 }, { color: [1, 1, 1, 1], stop: 1 }]);
     this.changeTransferFunc(tf.data, tf.length);  // viewer.ts:377-385
   }
+  setEnvironment(env) { // viewer.ts:1073-1078; null removes the map (directional light only)
+    if (env) native.uploadEnvironment(this.ctx, env.floats, env.width, env.height);
+    else native.uploadEnvironment(this.ctx, null, 0, 0);
+    this.environment = env || null;
+    this.restartRendering();
+  }
+  get envStrength() { return this.environment ? this.environment.strength : (this._envStrength === undefined ? 1 : this._envStrength); }
+  set envStrength(v) { this._envStrength = v; if (this.environment) this.environment.strength = v; }
   dispose() { if (this.ctx) { native.destroy(this.ctx); this.ctx = null; } }
 
   get renderMode() { return this.settings.renderMode; }
@@ -239,7 +267,7 @@ class Volxel3DDicomRenderer {
     p.set('density_transform', combined); p.set('density_transform_inv', M.invert(combined));
     p.set('sample_range', s.sampleRange);
     p.set('light_dir', s.lightDir); p.set('env_strength', this.envStrength);
-    p.set('show_environment', s.showEnvironment ? 1 : 0); p.set('use_env', 0); p.set('bounces', s.bounces);
+    p.set('show_environment', s.showEnvironment ? 1 : 0); p.set('use_env', s.useEnv && this.environment ? 1 : 0); p.set('bounces', s.bounces);
     p.set('res', [this.width, this.height]); p.set('debug_hits', s.debugHits ? 1 : 0);
     p.set('render_mode', RenderMode[s.renderMode]);
     p.set('dvr_step_voxels', s.dvrStepVoxels); p.set('dvr_ert_tau', -Math.log(s.dvrErtEpsilon));
@@ -270,6 +298,44 @@ class Volxel3DDicomRenderer {
       this.frameIndex++;
     }
   }
+  /** startBenchmark (viewer.ts:856-890) + the result record of viewer.ts:1229-1241.  `volumes` maps an
+   *  entry's "zip" string to a brick-grid message (container I/O is outside the path). */
+  startBenchmark(collection, volumes = {}) {
+    if (!collection || !Array.isArray(collection.sharedSettings) || !Array.isArray(collection.benchmarks)) throw new Error('Malformed benchmark collection.');
+    const results = [], savedPreview = this.lowResPreview;
+    this.lowResPreview = true;                    // the viewer's framebuffer sizing is part of the scenario
+    try {
+      for (const b of collection.benchmarks) {
+        if (b.zip !== undefined) {
+          if (!volumes[b.zip]) throw new Error(`benchmark volume not provided: ${b.zip}`);
+          this.setupFromGrid(volumes[b.zip]);
+        }
+        if (b.env !== undefined) throw new Error('benchmark entry asks for an environment map URL; pass the decoded map with setEnvironment() before the run');
+        this.restoreSettings(typeof b.settings === 'number' ? collection.sharedSettings[b.settings] : b.settings);
+        if (b.renderMode) this.renderMode = b.renderMode;
+        this.restartRendering();
+        let total = 0;
+        while (this.frameIndex <= this.settings.maxSamples) {   // viewer.ts:1194
+          const t0 = process.hrtime.bigint();
+          this.render(1); this.finish();                          // viewer.ts:1213-1218
+          total += Number(process.hrtime.bigint() - t0) / 1e6;
+        }
+        const rf = this.settings.resolutionFactor;
+        results.push(JSON.parse(JSON.stringify({
+          name: b.name, settings: this.settings, timePerSample: total / this.frameIndex, totalTime: total,
+          viewport: [0, 0, rf * this.canvasWidth, rf * this.canvasHeight],
+          device: { platform: process.platform, userAgent: `node ${process.version} / volxel_hip ${native.version()}`,
+            hardwareConcurrency: require('os').cpus().length, screen: { width: this.canvasWidth, height: this.canvasHeight, pixelRatio: 1 },
+            gpu: { vendor: 'AMD', renderer: 'gfx950', version: 'HIP' } },
+          timestamp: new Date(),
+        })));
+      }
+    } finally {
+      this.lowResPreview = savedPreview;
+      if (!savedPreview) { this.resolutionFactor = 1.0; this.resizeFramebuffersToCanvas(); }
+    }
+    return results;
+  }
   finish() { native.finish(this.ctx); }
   readAccum() { const o = new Float32Array(this.width * this.height * 4); native.readAccum(this.ctx, o); return o; }
   readDisplay() { // the blit to the canvas (NEAREST, viewer.ts:310-311,1253-1265)
@@ -281,4 +347,4 @@ class Volxel3DDicomRenderer {
   resetCounters() { native.resetCounters(this.ctx); }
 }
 
-module.exports = { Volxel3DDicomRenderer, VolxelRenderMode: RenderMode, generateTransferFunction, Camera, native };
+module.exports = { Volxel3DDicomRenderer, Environment, VolxelRenderMode: RenderMode, generateTransferFunction, Camera, native };

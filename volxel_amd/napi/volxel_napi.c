@@ -152,6 +152,29 @@ static napi_value n_upload_transfer(napi_env env, napi_callback_info info) {
   return NULL;
 }
 
+/* uploadEnvironment(ctx, Float32Array rgba | null, width, height): `new Environment(gl, env)` */
+static napi_value n_upload_environment(napi_env env, napi_callback_info info) {
+  napi_value a[4];
+  if (!get_args(env, info, 4, a)) return NULL;
+  VxContext* c = get_ctx(env, a[0]);
+  if (!c) return NULL;
+  napi_valuetype t;
+  NAPI_OK(napi_typeof(env, a[1], &t));
+  if (t == napi_null || t == napi_undefined) {
+    if (vx_upload_environment(c, NULL, 0, 0) != VX_OK) return throw_msg(env, vx_last_error(c));
+    return NULL;
+  }
+  void* d;
+  size_t n;
+  uint32_t w, h;
+  if (!typed(env, a[1], napi_float32_array, &d, &n)) return NULL;
+  NAPI_OK(napi_get_value_uint32(env, a[2], &w));
+  NAPI_OK(napi_get_value_uint32(env, a[3], &h));
+  if (n < (size_t)w * h * 4) return throw_msg(env, "uploadEnvironment: data shorter than width*height*4");
+  if (vx_upload_environment(c, (const float*)d, w, h) != VX_OK) return throw_msg(env, vx_last_error(c));
+  return NULL;
+}
+
 /* setParams(ctx, ArrayBuffer holding one VxParams) */
 static napi_value n_set_params(napi_env env, napi_callback_info info) {
   napi_value a[2];
@@ -450,7 +473,7 @@ static napi_value grid_to_object(napi_env env, VxBrickGrid* g) {
 static napi_value init(napi_env env, napi_value exports) {
   static const struct { const char* name; napi_callback fn; } fns[] = {
       {"create", n_create}, {"destroy", n_destroy}, {"uploadVolume", n_upload_volume},
-      {"uploadTransfer", n_upload_transfer}, {"setParams", n_set_params}, {"sizeofParams", n_sizeof_params},
+      {"uploadTransfer", n_upload_transfer}, {"uploadEnvironment", n_upload_environment}, {"setParams", n_set_params}, {"sizeofParams", n_sizeof_params},
       {"resize", n_resize}, {"setLayout", n_set_layout}, {"renderFrame", n_render_frame}, {"finish", n_finish},
       {"readAccum", n_read_accum}, {"readDisplay", n_read_display},
       {"readDisplayScaled", n_read_display_scaled}, {"getCounters", n_get_counters},
