@@ -100,17 +100,17 @@ def traffic_from_profile(a):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=60)
+    ap.add_argument("--steps", type=int, default=64)
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--width", type=int, default=1920)
     ap.add_argument("--height", type=int, default=1080)
     ap.add_argument("--volume", type=int, default=512)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--layout", type=int, default=None, help="0 reference, 1 cellquad (default), 2 brickf32 + LDS tiles")
-    ap.add_argument("--gather-every", type=int, default=8,
+    ap.add_argument("--gather-every", type=int, default=32,
                     help="N>1: all_gather the framebuffer once per this many accumulation frames")
-    ap.add_argument("--frames-per-launch", type=int, default=8,
-                    help="independent accumulation frames rendered by one kernel launch (1..8)")
+    ap.add_argument("--frames-per-launch", type=int, default=32,
+                    help="independent accumulation frames rendered by one kernel launch (1..32)")
     ap.add_argument("--no-skip-variant", action="store_true", help="do not run the secondary measurement with skipping")
     ap.add_argument("--force-gather", action="store_true", help="run the gather path with one rank too (testing)")
     a = ap.parse_args()
@@ -155,7 +155,7 @@ def main():
         gathered = torch.empty(world * slab.numel(), dtype=torch.float32, device="cuda")
         image = torch.empty(a.height * a.width * 4, dtype=torch.float32, device="cuda")
 
-    P = max(1, min(8, a.frames_per_launch))
+    P = max(1, min(32, a.frames_per_launch))
 
     def batch(f0, n):
         """n accumulation frames f0.. (n <= P): one launch, then -- at display cadence -- the gather"""
@@ -190,8 +190,9 @@ def main():
 
     def run(first, count):
         done = 0
-        while done < count:
-            n = min(P, count - done)
+        while done < count:                   # equal launches: 40 frames at P = 32 go as 20 + 20
+            launches_left = -(-(count - done) // P)
+            n = -(-(count - done) // launches_left)
             batch(first + done, n)
             done += n
 

@@ -769,8 +769,10 @@ static int ensure_pipes(VxContext* c, int n) {
     p.dc = nullptr;
   }
   if ((int)c->pipes.size() < n) c->pipes.resize(n);
-  for (auto& p : c->pipes) {
-    if (!p.stream) VX_HIP(c, hipStreamCreateWithFlags(&p.stream, hipStreamNonBlocking));
+  for (size_t i = 0; i < c->pipes.size(); ++i) {
+    auto& p = c->pipes[i];
+    // streams only for the rolling-window path (<= 8 slots); the multi-frame kernel needs none
+    if (i < 8 && !p.stream) VX_HIP(c, hipStreamCreateWithFlags(&p.stream, hipStreamNonBlocking));
     if (!p.done) VX_HIP(c, hipEventCreateWithFlags(&p.done, hipEventDisableTiming));
     if (!p.merged) VX_HIP(c, hipEventCreateWithFlags(&p.merged, hipEventDisableTiming));
     p.has_merged = false;
@@ -847,7 +849,7 @@ int vx_render_frames(VxContext* c, uint32_t first_frame, uint32_t count, const f
   VX_HIP(c, hipEventRecord(ev.a, c->stream));
   // rolling window: frame f renders on slot f % in_flight as soon as that slot's previous result has
   // been blended; the blends happen on the main stream, in frame order
-  const uint32_t P = (uint32_t)in_flight;
+  const uint32_t P = (uint32_t)(in_flight > 8 ? 8 : in_flight);  // streams; more only costs queue slots
   const uint32_t nq = (uint32_t)c->slab_quads;
   for (; done < count && le == hipSuccess; ++done) {
     auto& p = c->pipes[c->pipe_next % P];

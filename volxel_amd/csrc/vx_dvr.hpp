@@ -68,9 +68,9 @@ VXD void dvr_store(const VxParams& p, const DevVolume& dv, const DvrRay& r, floa
 // of logical block order[s / count], so the longest blocks of all frames start first and the
 // latency-bound tail is paid once per `count` frames.  count == 1 is the plain per-frame launch.
 struct MultiOut {
-  float4* out[8];
-  DevCounters* dc[8];
-  uint32_t frame[8];
+  float4* out[MERGE_MAX];
+  DevCounters* dc[MERGE_MAX];
+  uint32_t frame[MERGE_MAX];
   uint32_t count;
 };
 

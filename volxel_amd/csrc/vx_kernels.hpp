@@ -197,7 +197,7 @@ __global__ __launch_bounds__(256) void build_brickf32(const DevVolume v, float* 
 }
 
 // ---- ordered running-mean blend of pipelined frame results (fragment.frag:158 applied n times) ----
-constexpr int MERGE_MAX = 8;
+constexpr int MERGE_MAX = 32;  // frames per launch of the multi-frame DVR kernel (MultiOut)
 struct MergeArgs {
   const float4* result[MERGE_MAX];
   float weight[MERGE_MAX];
