@@ -76,10 +76,25 @@ def cpu_baseline(r, msg, crop=(1920, 1080)):
     _, c = O.render(p, vol, tf, L, frame_index=0, rect=(x0, x0 + crop[0], y0, y0 + crop[1]), threads=threads,
                     env=env)
     dt = time.perf_counter() - t0
+    # single-thread figure on the centred 480x270 crop (1/16 of 1080p), BASELINE.md section 4
+    sw, sh = min(480, W), min(270, H)
+    sx, sy = (W - sw) // 2, (H - sh) // 2
+    t1 = time.perf_counter()
+    _, c1 = O.render(p, vol, tf, L, frame_index=0, rect=(sx, sx + sw, sy, sy + sh), threads=1, env=env)
+    dt1 = time.perf_counter() - t1
+    model = ""
+    try:
+        with open("/proc/cpuinfo") as f:
+            model = next((ln.split(":", 1)[1].strip() for ln in f if ln.startswith("model name")), "")
+    except OSError:
+        pass
     return {"value": round(c.samples / dt / 1e9, 5), "unit": "Gsamples/s", "cores": threads, "kind": "port",
             "sample": f"centred {crop[0]}x{crop[1]} crop of the same frame, {c.samples} samples in {dt:.2f} s "
                       f"({threads} threads over row bands)",
-            "ms_per_frame_crop": round(dt * 1e3, 1)}
+            "ms_per_frame_crop": round(dt * 1e3, 1),
+            "single_thread": {"value": round(c1.samples / dt1 / 1e9, 5), "unit": "Gsamples/s", "cores": 1,
+                              "sample": f"centred {sw}x{sh} crop, {c1.samples} samples in {dt1:.2f} s"},
+            "cpu_model": model, "host_cores": os.cpu_count()}
 
 
 def traffic_from_profile(a):
@@ -90,7 +105,8 @@ def traffic_from_profile(a):
     key = {None: "cellquad", 0: "reference", 1: "cellquad", 2: "brickf32"}[a.layout]
     try:
         t = json.load(open(path))[key]
-        if (t["width"], t["height"], t["volume"]) != (a.width, a.height, a.volume):
+        if (t["width"], t["height"], t["volume"], t.get("frames_per_launch", 32)) != \
+                (a.width, a.height, a.volume, max(1, min(32, a.frames_per_launch))):
             return {"traffic": None}
         return {"traffic": int(t["hbm_bytes_per_launch"]), "traffic_source": t["source"]}
     except Exception:

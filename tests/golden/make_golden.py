@@ -70,6 +70,40 @@ def render_case(oracle, name):
     return oracle.render(p, grid, tf, L, frame_index=frame, threads=1, env=env)
 
 
+def tf_table_restated(colors, steps=128):
+    """utils/data.ts:21-60 restated on its own (float64 like JavaScript, then Float32Array)"""
+    st = sorted(colors, key=lambda c: c["stop"])
+    cur, out = -1, []
+    for i in range(steps):
+        pos = i / steps
+        if cur < 0:
+            if st[0]["stop"] >= pos:
+                cur = 0
+                out.append(list(st[0]["color"]))
+            else:
+                out.append([0, 0, 0, 0])
+            continue
+        nxt = st[cur + 1] if cur + 1 < len(st) else None
+        if nxt is None:
+            out.append(list(st[cur]["color"]))
+            continue
+        prog = (pos - st[cur]["stop"]) / (nxt["stop"] - st[cur]["stop"])
+        if prog >= 1.0:
+            out.append(list(nxt["color"]))
+            cur += 1
+            continue
+        out.append([(1 - prog) * a + prog * b for a, b in zip(st[cur]["color"], nxt["color"])])
+    return np.asarray(out, dtype=np.float64).astype(np.float32).ravel()
+
+
+def tf_fixture():
+    """the two 128-entry tables SURVEY 8(c) asks for: viewer default ramp, benchmark.json stops"""
+    from volxel_amd.settings import BENCHMARK_SETTINGS
+    default = [{"color": [1, 1, 1, 0], "stop": 0}, {"color": [1, 1, 1, 1], "stop": 1}]   # viewer.ts:378-384
+    return {"default": tf_table_restated(default),
+            "benchmark": tf_table_restated(BENCHMARK_SETTINGS["transfer"]["transfer"]["colors"])}
+
+
 ENV_KAT_U = [(0.0, 0.0), (0.5, 0.5), (0.25, 0.75), (0.999999, 0.000001), (0.6369617, 0.26978672),
              (0.04097353, 0.01652764), (0.8132702, 0.91275555), (0.123, 0.987)]
 
@@ -99,6 +133,7 @@ def main():
                             rays=np.uint64(c.rays))
         print(name, img.shape, "samples", c.samples, "max", float(img[..., :3].max()))
     np.savez_compressed(os.path.join(HERE, "env_default.npz"), **env_fixture(O))
+    np.savez_compressed(os.path.join(HERE, "tf_tables.npz"), **tf_fixture())
     L = O.lib()
     kat = {"tea": [], "wang": [], "xoshiro": []}
     for v0, v1 in [(0, 0), (1, 0), (0, 1), (42 * 12345, 17), (0xFFFFFFFF, 0xFFFFFFFF)]:

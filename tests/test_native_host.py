@@ -292,3 +292,17 @@ def test_benchmark_collection_schema():
               "resolutionFactor"):                      # viewer.ts:147-163
         assert k in d
     assert d["maxSamples"] == 2000 and d["renderMode"] == "default" and d["sampleRange"] == [0.0, 1.0]
+
+
+def test_transfer_tables_match_committed_fixture():
+    """the viewer's default ramp and the benchmark.json stops as 128-entry tables:
+    fixture = independent restatement of data.ts:21-60 in tests/golden/make_golden.py"""
+    from tests.common import benchmark_tf
+    from tests.golden.make_golden import tf_fixture
+    from volxel_amd import default_transfer_function
+    want = np.load(os.path.join(os.path.dirname(__file__), "golden", "tf_tables.npz"))
+    fresh = tf_fixture()
+    for k in ("default", "benchmark"):
+        assert np.array_equal(fresh[k], want[k])
+    assert np.array_equal(default_transfer_function()[0], want["default"])
+    assert np.array_equal(benchmark_tf()[0], want["benchmark"])
