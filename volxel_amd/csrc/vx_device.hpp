@@ -198,6 +198,23 @@ VXD float bf_voxel(const DevVolume& v, int x, int y, int z) {
   return v.bf[(size_t)b * 512u + l];
 }
 
+// A4 through the device layouts: the decoded value of voxel (x,y,z) is the .x tap of cellquad cell
+// (x,y,z) / the brickf32 voxel -- one load instead of the range -> pointer -> atlas chain.  Same bits:
+// both layouts were filled by lookup_density_brick.
+template <int LAYOUT>
+VXD float lookup_density_nearest(const DevVolume& v, int x, int y, int z) {
+  if (LAYOUT == LAYOUT_CQ) {
+    if ((uint32_t)x >= v.extent[0] || (uint32_t)y >= v.extent[1] || (uint32_t)z >= v.extent[2]) return 0.0f;
+    uint32_t cx = (uint32_t)x + 1u, cy = (uint32_t)y + 1u, cz = (uint32_t)z + 1u;
+    uint32_t b = ((cz >> 3) * v.cq_bc[1] + (cy >> 3)) * v.cq_bc[0] + (cx >> 3);
+    size_t o = (size_t)b * CQ_BRICK_QUADS + ((cz & 7u) * 64u + (cy & 7u) * 8u + (cx & 7u));
+    return reinterpret_cast<const float*>(v.cq + o)[0];
+  } else if (LAYOUT == LAYOUT_BF) {
+    return bf_voxel(v, x, y, z);
+  }
+  return lookup_density_brick(v, x, y, z);
+}
+
 // A5: lookup_density_trilinear, common.glsl:61-69
 template <int LAYOUT>
 VXD float lookup_density_trilinear(const DevVolume& v, float density_scale, V3 p) {

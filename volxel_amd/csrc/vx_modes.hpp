@@ -21,7 +21,7 @@ struct Frame {
   VXD float density_stochastic(V3 ipos, Rng& s) const {
     int tap[3];
     stochastic_tricubic_filter(ipos, s, tap);
-    return p.volume_density_scale * lookup_density_brick(v, tap[0], tap[1], tap[2]);
+    return p.volume_density_scale * lookup_density_nearest<LAYOUT>(v, tap[0], tap[1], tap[2]);
   }
   VXD bool slab(const Ray& r, float& near, float& far) const {
     return ray_box_intersection(r, p.volume_aabb_min, p.volume_aabb_max, near, far);

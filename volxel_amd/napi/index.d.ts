@@ -22,7 +22,9 @@ export declare class Volxel3DDicomRenderer {
   setEnvironment(env: Environment | null): void;
   settings: Record<string, any>; camera: Camera; envStrength: number; frameIndex: number;
   renderMode: keyof typeof VolxelRenderMode;
-  /** restartFromFiles (viewer.ts:833-866) for slices already read into memory */
+  restartFromFiles(files: (string | Uint8Array)[], threads?: number): void;
+  setupEnv(env: { width: number; height: number; floats: Float32Array }): void;
+  /** restartFromFiles for slices already read into memory */
   restartFromBytes(files: Uint8Array[], threads?: number): void;
   restartFromVoxels(voxels: Uint16Array, dims: [number, number, number], spacing?: [number, number, number], maxValue?: number, threads?: number): void;
   setupFromGrid(grid: BrickGridMessage): void;

@@ -187,7 +187,14 @@ class Volxel3DDicomRenderer {
     this.settings.renderMode = to; this.restartRendering();
   }
 
-  /** restartFromFiles (viewer.ts:833-866) once the File objects are read: one Uint8Array per slice */
+  /** restartFromFiles (viewer.ts:963-975): DICOM slice paths (or Uint8Arrays) in stacking order */
+  restartFromFiles(files, threads = 0) {
+    const fs = require('fs');
+    this.restartFromBytes(files.map(f => (typeof f === 'string' ? new Uint8Array(fs.readFileSync(f)) : f)), threads);
+  }
+  /** setupEnv (viewer.ts:1073-1078): { width, height, floats } with row 0 = top */
+  setupEnv(env) { this.setEnvironment(new Environment(env.floats, env.width, env.height)); }
+  /** the same once the files are in memory: one Uint8Array per slice (worker.ts:101-104) */
   restartFromBytes(files, threads = 0) {
     this.setupFromGrid(native.readDicomsToGrid(files, threads));
   }

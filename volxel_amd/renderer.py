@@ -171,6 +171,27 @@ class Volxel3DRenderer:
         self.settings.render_mode = to
         self.restart_rendering()
 
+    # -- viewer.ts:963-975 restartFromFiles (+ worker.ts:77-104: files -> bytes -> read_dicoms_to_grid)
+    def restart_from_files(self, files, n_threads: int = 0):
+        """files: DICOM slices as paths or bytes objects, in stacking order (the reference does not
+        sort them either, lib.rs:150-176).  ZIP / URL variants are container I/O outside the path."""
+        from .preprocessor import read_dicoms_to_grid
+        blobs = []
+        for f in files:
+            if isinstance(f, (bytes, bytearray, memoryview)):
+                blobs.append(bytes(f))
+            else:
+                with open(f, "rb") as fh:
+                    blobs.append(fh.read())
+        self.setup_from_grid(read_dicoms_to_grid(blobs, n_threads))
+
+    # -- viewer.ts:1073-1078 setupEnv(WasmWorkerMessageEnvReturn) -----------------------------
+    def setup_env(self, env_message):
+        """env_message: mapping / object with width, height, floats (row 0 = top)"""
+        g = (lambda k: env_message[k]) if isinstance(env_message, dict) else (lambda k: getattr(env_message, k))
+        # a new Environment starts at strength 1 (environment.ts:15)
+        self.set_environment(Environment(g("floats"), int(g("width")), int(g("height")), 1.0))
+
     # -- viewer.ts:1080-1145 ------------------------------------------------------------
     def setup_from_grid(self, grid):
         """grid: preprocessor.BrickGridMessage (= WasmWorkerMessageDicomReturn)."""
