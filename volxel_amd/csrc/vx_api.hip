@@ -62,6 +62,8 @@ struct VxContext {
   float4* image = nullptr;
   float4* env_tex = nullptr;   // environment map, GL row order
   float* env_imp = nullptr;    // importance pyramid
+  float4* env_impq = nullptr;  // the pyramid as sibling quads (sample_environment)
+  float env_avg_w = 0.0f;
   uint32_t env_w = 0, env_h = 0;
   uchar4* display = nullptr;
   uint32_t display_cap = 0;  // pixels
@@ -109,6 +111,11 @@ struct VxContext {
     hipError_t e_ = (expr);                                                                 \
     if (e_ != hipSuccess) VX_FAIL(ctx, VX_ERR_DEVICE, "%s: %s", #expr, hipGetErrorString(e_)); \
   } while (0)
+
+// every entry point that touches the device first makes the context's device current for the
+// calling thread (a host with several contexts / devices must not depend on its own hipSetDevice)
+#define VX_DEV(ctx) VX_HIP(ctx, hipSetDevice((ctx)->device))
+
 
 static void free_volume(VxContext* c) {
   for (void* p : c->vol_allocs) (void)hipFree(p);
@@ -411,6 +418,7 @@ void vx_destroy(VxContext* c) {
   if (c->tf) (void)hipFree(c->tf);
   if (c->env_tex) (void)hipFree(c->env_tex);
   if (c->env_imp) (void)hipFree(c->env_imp);
+  if (c->env_impq) (void)hipFree(c->env_impq);
   if (c->skip_dev) (void)hipFree(c->skip_dev);
   if (c->slab) (void)hipFree(c->slab);
   if (c->image) (void)hipFree(c->image);
@@ -432,6 +440,7 @@ const char* vx_last_error(const VxContext* c) { return c ? c->err.c_str() : g_cr
 
 int vx_set_stream(VxContext* c, void* s) {
   if (!c) return VX_ERR_INVALID;
+  VX_DEV(c);
   (void)hipStreamSynchronize(c->stream);
   c->stream = s ? (hipStream_t)s : c->own_stream;
   return VX_OK;
@@ -475,6 +484,7 @@ int vx_upload_volume(VxContext* c, const uint32_t* indirection, const uint32_t i
                      const uint32_t atlas_size[3], int n_mips, const uint16_t* const* mip_data,
                      const uint32_t (*mip_size)[3], const uint32_t index_extent[3]) {
   if (!c) return VX_ERR_INVALID;
+  VX_DEV(c);
   if (!indirection || !range || !ind_size || !range_size || !atlas_size || !index_extent)
     VX_FAIL(c, VX_ERR_INVALID, "vx_upload_volume: null argument");
   if (n_mips != 3 || !mip_data || !mip_size)
@@ -546,6 +556,7 @@ int vx_upload_volume(VxContext* c, const uint32_t* indirection, const uint32_t i
 
 int vx_set_layout(VxContext* c, int layout) {
   if (!c) return VX_ERR_INVALID;
+  VX_DEV(c);
   if (layout != VX_LAYOUT_REFERENCE && layout != VX_LAYOUT_CELLQUAD && layout != VX_LAYOUT_BRICKF32)
     VX_FAIL(c, VX_ERR_INVALID, "vx_set_layout: unknown layout %d", layout);
   if (layout == c->layout) return VX_OK;
@@ -561,6 +572,7 @@ int vx_set_layout(VxContext* c, int layout) {
 
 int vx_upload_transfer(VxContext* c, const float* rgba, uint32_t length) {
   if (!c) return VX_ERR_INVALID;
+  VX_DEV(c);
   if (!rgba || length == 0) VX_FAIL(c, VX_ERR_INVALID, "vx_upload_transfer: empty transfer function");
   VX_HIP(c, hipStreamSynchronize(c->stream));
   if (c->tf) (void)hipFree(c->tf);
@@ -582,8 +594,10 @@ int vx_upload_environment(VxContext* c, const float* rgba, uint32_t w, uint32_t 
     if (p.stream) VX_HIP(c, hipStreamSynchronize(p.stream));
   if (c->env_tex) (void)hipFree(c->env_tex);
   if (c->env_imp) (void)hipFree(c->env_imp);
+  if (c->env_impq) (void)hipFree(c->env_impq);
   c->env_tex = nullptr;
   c->env_imp = nullptr;
+  c->env_impq = nullptr;
   c->env_w = c->env_h = 0;
   if (!rgba) return VX_OK;
   if (w == 0 || h == 0 || w > 16384 || h > 16384)
@@ -593,6 +607,7 @@ int vx_upload_environment(VxContext* c, const float* rgba, uint32_t w, uint32_t 
     memcpy(flipped.data() + (size_t)(h - 1 - y) * w * 4, rgba + (size_t)y * w * 4, (size_t)w * 16);
   VX_HIP(c, hipMalloc(&c->env_tex, flipped.size() * sizeof(float)));
   VX_HIP(c, hipMalloc(&c->env_imp, (size_t)IMP_FLOATS * sizeof(float)));
+  VX_HIP(c, hipMalloc(&c->env_impq, (size_t)IMPQ_QUADS * sizeof(float4)));
   VX_HIP(c, hipMemcpy(c->env_tex, flipped.data(), flipped.size() * sizeof(float), hipMemcpyHostToDevice));
   c->env_w = w;
   c->env_h = h;
@@ -602,13 +617,21 @@ int vx_upload_environment(VxContext* c, const float* rgba, uint32_t w, uint32_t 
     uint32_t n = (IMP_DIM >> k) * (IMP_DIM >> k);
     hipLaunchKernelGGL(build_importance_mip, dim3((n + 255) / 256), dim3(256), 0, c->stream, c->env_imp, k);
   }
+  for (uint32_t k = 0; k + 1 < IMP_LEVELS; ++k) {
+    uint32_t n = (IMP_DIM >> (k + 1)) * (IMP_DIM >> (k + 1));
+    hipLaunchKernelGGL(build_importance_quads, dim3((n + 255) / 256), dim3(256), 0, c->stream, c->env_imp,
+                       c->env_impq, k);
+  }
   VX_HIP(c, hipGetLastError());
+  VX_HIP(c, hipMemcpyAsync(&c->env_avg_w, c->env_imp + (IMP_FLOATS - 1), sizeof(float),
+                           hipMemcpyDeviceToHost, c->stream));
   VX_HIP(c, hipStreamSynchronize(c->stream));
   return VX_OK;
 }
 
 int vx_debug_read_importance(VxContext* c, float* out) {
   if (!c || !out) return VX_ERR_INVALID;
+  VX_DEV(c);
   if (!c->env_imp) VX_FAIL(c, VX_ERR_INVALID, "vx_debug_read_importance: no environment uploaded");
   VX_HIP(c, hipStreamSynchronize(c->stream));
   VX_HIP(c, hipMemcpy(out, c->env_imp, (size_t)IMP_FLOATS * sizeof(float), hipMemcpyDeviceToHost));
@@ -617,6 +640,7 @@ int vx_debug_read_importance(VxContext* c, float* out) {
 
 int vx_set_params(VxContext* c, const VxParams* p) {
   if (!c || !p) return VX_ERR_INVALID;
+  VX_DEV(c);
   if (p->render_mode < VX_MODE_DEFAULT || p->render_mode > VX_MODE_DVR_PHONG)
     VX_FAIL(c, VX_ERR_INVALID, "vx_set_params: unknown render mode %d", p->render_mode);
   if (p->shard_count < 1 || p->shard_rank < 0 || p->shard_rank >= p->shard_count)
@@ -661,6 +685,8 @@ static int prepare_render(VxContext* c, dim3& grid) {
     VX_FAIL(c, VX_ERR_INVALID, "vx_render_frame: use_env = 1 without vx_upload_environment");
   c->dv.env_tex = c->env_tex;
   c->dv.env_imp = c->env_imp;
+  c->dv.env_impq = c->env_impq;
+  c->dv.env_avg_w = c->env_avg_w;
   c->dv.env_w = c->env_w;
   c->dv.env_h = c->env_h;
   {
@@ -726,6 +752,7 @@ static int take_events(VxContext* c, EventPair& ev) {
 
 int vx_render_frame(VxContext* c, uint32_t frame_index, float sample_weight) {
   if (!c) return VX_ERR_INVALID;
+  VX_DEV(c);
   dim3 grid;
   int rc = prepare_render(c, grid);
   if (rc) return rc;
@@ -791,6 +818,7 @@ static int ensure_pipes(VxContext* c, int n) {
 // calls).  Hides the latency-bound tail of one frame behind the bulk of the next ones.
 int vx_render_frames(VxContext* c, uint32_t first_frame, uint32_t count, const float* weights, int in_flight) {
   if (!c || (!weights && count)) return VX_ERR_INVALID;
+  VX_DEV(c);
   if (in_flight > MERGE_MAX) in_flight = MERGE_MAX;
   uint32_t done = 0;
   // frames that still refresh the launch order, and the degenerate cases, go one by one
@@ -879,12 +907,14 @@ int vx_render_frames(VxContext* c, uint32_t first_frame, uint32_t count, const f
 
 int vx_finish(VxContext* c) {
   if (!c) return VX_ERR_INVALID;
+  VX_DEV(c);
   VX_HIP(c, hipStreamSynchronize(c->stream));
   return VX_OK;
 }
 
 int vx_detile(VxContext* c, const void* gathered, void* image_out) {
   if (!c || !gathered || !image_out) return VX_ERR_INVALID;
+  VX_DEV(c);
   dim3 grid((c->W + 15) / 16, (c->H + 15) / 16);
   hipLaunchKernelGGL(detile, grid, dim3(256), 0, c->stream, (const float4*)gathered, (float4*)image_out, c->tm);
   VX_HIP(c, hipGetLastError());
@@ -910,6 +940,7 @@ static int own_image(VxContext* c) {
 
 int vx_read_accum(VxContext* c, float* out) {
   if (!c || !out) return VX_ERR_INVALID;
+  VX_DEV(c);
   int rc = own_image(c);
   if (rc) return rc;
   VX_HIP(c, hipMemcpyAsync(out, c->image, (size_t)c->W * c->H * sizeof(float4), hipMemcpyDeviceToHost, c->stream));
@@ -919,6 +950,7 @@ int vx_read_accum(VxContext* c, float* out) {
 
 int vx_read_display_scaled(VxContext* c, uint8_t* out, uint32_t ow, uint32_t oh, float exposure, float gamma) {
   if (!c || !out) return VX_ERR_INVALID;
+  VX_DEV(c);
   if (ow == 0 || oh == 0 || (uint64_t)ow * oh > (1ull << 28)) {
     c->err = "vx_read_display_scaled: bad canvas size";
     return VX_ERR_INVALID;
@@ -968,6 +1000,7 @@ int vx_slab_device_ptr(VxContext* c, void** p) {
 
 int vx_get_counters(VxContext* c, VxCounters* out) {
   if (!c || !out) return VX_ERR_INVALID;
+  VX_DEV(c);
   VX_HIP(c, hipStreamSynchronize(c->stream));
   drain_events(c);
   int rc = fold_counters(c);
@@ -987,6 +1020,7 @@ int vx_get_counters(VxContext* c, VxCounters* out) {
 
 int vx_reset_counters(VxContext* c) {
   if (!c) return VX_ERR_INVALID;
+  VX_DEV(c);
   VX_HIP(c, hipStreamSynchronize(c->stream));
   drain_events(c);
   {
@@ -1030,6 +1064,7 @@ int vx_debug_build_skip_mask(const uint32_t* range_packed, const uint32_t brick_
 // test hook (not part of the reference boundary): the device's unorm8 decode table
 int vx_debug_unorm_table(VxContext* c, float* out256) {
   if (!c || !out256) return VX_ERR_INVALID;
+  VX_DEV(c);
   float* d = nullptr;
   VX_HIP(c, hipMalloc(&d, 256 * sizeof(float)));
   hipLaunchKernelGGL(unorm_table, dim3(1), dim3(256), 0, c->stream, d);

@@ -43,9 +43,18 @@ struct DevVolume {
   const float4* env_tex;        // nullptr: none (directional light only)
   uint32_t env_w, env_h;
   const float* env_imp;         // levels 0..9 of the 512^2 map back to back (imp_offset)
+  const float4* env_impq;       // the same levels 0..8 as 2x2 sibling quads, one 16-byte load per level
+  float env_avg_w;              // level 9 (the mean importance)
 };
 
 constexpr uint32_t IMP_DIM = 512, IMP_LEVELS = 10, IMP_FLOATS = 349525;
+// quads of level k (children of the texels of level k+1): (IMP_DIM >> (k+1))^2 float4, row major
+VXD constexpr uint32_t impq_offset(uint32_t level) {
+  uint32_t o = 0;
+  for (uint32_t k = 0; k < level; ++k) o += (IMP_DIM >> (k + 1)) * (IMP_DIM >> (k + 1));
+  return o;
+}
+constexpr uint32_t IMPQ_QUADS = 87381;
 VXD constexpr uint32_t imp_offset(uint32_t level) {
   uint32_t o = 0;
   for (uint32_t k = 0; k < level; ++k) o += (IMP_DIM >> k) * (IMP_DIM >> k);
@@ -423,26 +432,27 @@ VXD V3 lookup_environment(const VxParams& p, const DevVolume& dv, V3 dir) {
 VXD float pdf_environment(const VxParams& p, const DevVolume& dv, V3 dir) {
   const float inv_4pi = 1.0f / (4.0f * 3.14159265358979323846f);
   V3 le = lookup_environment(p, dv, dir);
-  float avg_w = imp_fetch(dv.env_imp, 0, 0, (int)IMP_LEVELS - 1);
-  return env_luma(le) / avg_w * inv_4pi;
+  return env_luma(le) / dv.env_avg_w * inv_4pi;
 }
 // environment.glsl:35-79 (u_use_env = 1 only): hierarchical warp over the importance mips
 VXD float4 sample_environment(const VxParams& p, const DevVolume& dv, float u0, float u1, V3& w_i) {
   const float pi = 3.14159265358979323846f, inv_4pi = 1.0f / (4.0f * 3.14159265358979323846f);
   int px = 0, py = 0;
-  float sx = u0, sy = u1;
+  float sx = u0, sy = u1, wsel = 0.0f;
   for (int mip = (int)IMP_LEVELS - 2; mip >= 0; --mip) {
+    // the four texels pos*2 + {0,1}^2 of level `mip` are one quad, indexed by the parent texel
+    const int half = (int)(IMP_DIM >> (mip + 1));
+    float4 q = dv.env_impq[impq_offset((uint32_t)mip) + (uint32_t)(py * half + px)];
     px *= 2; py *= 2;
-    float w0 = imp_fetch(dv.env_imp, px, py, mip), w1 = imp_fetch(dv.env_imp, px + 1, py, mip);
-    float w2 = imp_fetch(dv.env_imp, px, py + 1, mip), w3 = imp_fetch(dv.env_imp, px + 1, py + 1, mip);
+    float w0 = q.x, w1 = q.y, w2 = q.z, w3 = q.w;
     float q0 = w0 + w2, q1 = w1 + w3;
     float d = q0 / gl_max(1e-8f, q0 + q1);
-    float wsel, qsel;
-    if (sx < d) { sx = sx / d; wsel = w0; qsel = q0; }
-    else { sx = (sx - d) / (1.0f - d); px += 1; wsel = w1; qsel = q1; }
+    float wtop, qsel;
+    if (sx < d) { sx = sx / d; wsel = w0; wtop = w2; qsel = q0; }
+    else { sx = (sx - d) / (1.0f - d); px += 1; wsel = w1; wtop = w3; qsel = q1; }
     float e = wsel / qsel;
     if (sy < e) { sy = sy / e; }
-    else { py += 1; sy = (sy - e) / (1.0f - e); }
+    else { py += 1; sy = (sy - e) / (1.0f - e); wsel = wtop; }
   }
   const float inv_dim = 1.0f / (float)IMP_DIM;
   float uvx = ((float)px + sx) * inv_dim, uvy = ((float)py + sy) * inv_dim;
@@ -451,8 +461,7 @@ VXD float4 sample_environment(const VxParams& p, const DevVolume& dv, float u0, 
   float sin_t = sinf(theta);
   w_i = v3(sin_t * cosf(phi), cosf(theta), sin_t * sinf(phi));
   V3 t = env_texture(dv.env_tex, dv.env_w, dv.env_h, uvx, uvy);
-  float avg_w = imp_fetch(dv.env_imp, 0, 0, (int)IMP_LEVELS - 1);
-  float pdf = imp_fetch(dv.env_imp, px, py, 0) / avg_w;
+  float pdf = wsel / dv.env_avg_w;  // wsel = texel (px,py) of level 0, env_avg_w = level 9
   return make_float4(p.env_strength * t.x, p.env_strength * t.y, p.env_strength * t.z, pdf * inv_4pi);
 }
 

@@ -296,6 +296,18 @@ __global__ __launch_bounds__(256) void build_importance_mip(float* __restrict__ 
   pyr[imp_offset(level) + i] = (((a + b) + c) + d) * 0.25f;
 }
 
+// sibling quads of every level 0..8 for sample_environment: one thread per quad
+__global__ __launch_bounds__(256) void build_importance_quads(const float* __restrict__ pyr, float4* __restrict__ quads,
+                                                               uint32_t level) {
+  uint32_t half = IMP_DIM >> (level + 1), n = half * 2;
+  uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= half * half) return;
+  uint32_t X = i % half, Y = i / half;
+  const float* src = pyr + imp_offset(level);
+  quads[impq_offset(level) + i] = make_float4(src[(size_t)(2 * Y) * n + 2 * X], src[(size_t)(2 * Y) * n + 2 * X + 1],
+                                              src[(size_t)(2 * Y + 1) * n + 2 * X], src[(size_t)(2 * Y + 1) * n + 2 * X + 1]);
+}
+
 // test hook: the unorm8 table
 __global__ void unorm_table(float* out) { out[threadIdx.x] = unorm8(threadIdx.x); }
 
