@@ -31,11 +31,15 @@ VXD bool block_to_tile(uint32_t b, const TileMap& tm, uint32_t& lt, uint32_t& su
 VXD bool wave_pixel(const TileMap& tm, uint32_t lt, uint32_t wt, uint32_t lane, int& px, int& py,
                     uint32_t& slab_index) {
   uint32_t t = lt * tm.shard_count + tm.shard_rank;
-  slab_index = (lt * 64u + wt) * 64u + lane;
+  // hardware lane -> pixel of the 8x8 wave tile in Morton order: the address coalescer merges the
+  // gathers of 4 consecutive lanes, and a 2x2 pixel block touches fewer cache lines than a 4x1 row.
+  // The slab keeps its row-major slot order (slot = y*8 + x), so only the lane that owns a pixel moves.
+  uint32_t lx = morton_x(lane), ly = morton_x(lane >> 1);
+  slab_index = (lt * 64u + wt) * 64u + ly * 8u + lx;
   if (t >= tm.n_tiles) return false;
   uint32_t tx = t % tm.tiles_x, ty = t / tm.tiles_x;
-  px = (int)(tx * 64u + morton_x(wt) * 8u + (lane & 7u));
-  py = (int)(ty * 64u + morton_x(wt >> 1) * 8u + (lane >> 3));
+  px = (int)(tx * 64u + morton_x(wt) * 8u + lx);
+  py = (int)(ty * 64u + morton_x(wt >> 1) * 8u + ly);
   return (uint32_t)px < tm.W && (uint32_t)py < tm.H;
 }
 
