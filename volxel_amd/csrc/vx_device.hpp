@@ -68,8 +68,15 @@ VXD bool skip_test(const uint32_t* bits, uint32_t sh, uint32_t d0, uint32_t d1, 
   return (bits[mi >> 5] >> (mi & 31u)) & 1u;
 }
 
-constexpr uint32_t CQ_SLICE_QUADS = 64;                  // 8x8 cells per z slice
+// cell order inside an apron brick: 9 z slices of 8x8 cells; inside a slice a 128-byte line (8 quads)
+// holds 4 x 2 cells (x, y), lines x-fastest.  (Tried: 8x1 rows = the plain x-fastest order, and
+// 2x2x2 blocks with z padded to 10 slices)
+constexpr uint32_t CQ_SLICE_QUADS = 64;
 constexpr uint32_t CQ_BRICK_QUADS = 9 * CQ_SLICE_QUADS;  // 576 float4 = 9216 B
+VXD uint32_t cq_cell(uint32_t lx, uint32_t ly, uint32_t lz) {  // local cell (0..7, 0..7, 0..8) -> quad index
+  return (lz << 6) | ((ly & 6u) << 3) | ((lx & 4u) << 1) | ((ly & 1u) << 2) | (lx & 3u);
+}
+VXD uint32_t cq_next_slice(uint32_t) { return CQ_SLICE_QUADS; }
 
 // ---------------------------------------------------------------------------------------
 // arithmetic helpers
@@ -216,7 +223,7 @@ VXD float lookup_density_nearest(const DevVolume& v, int x, int y, int z) {
     if ((uint32_t)x >= v.extent[0] || (uint32_t)y >= v.extent[1] || (uint32_t)z >= v.extent[2]) return 0.0f;
     uint32_t cx = (uint32_t)x + 1u, cy = (uint32_t)y + 1u, cz = (uint32_t)z + 1u;
     uint32_t b = ((cz >> 3) * v.cq_bc[1] + (cy >> 3)) * v.cq_bc[0] + (cx >> 3);
-    size_t o = (size_t)b * CQ_BRICK_QUADS + ((cz & 7u) * 64u + (cy & 7u) * 8u + (cx & 7u));
+    size_t o = (size_t)b * CQ_BRICK_QUADS + cq_cell(cx & 7u, cy & 7u, cz & 7u);
     return reinterpret_cast<const float*>(v.cq + o)[0];
   } else if (LAYOUT == LAYOUT_BF) {
     return bf_voxel(v, x, y, z);
@@ -238,9 +245,9 @@ VXD float lookup_density_trilinear(const DevVolume& v, float density_scale, V3 p
     uint32_t cx = (uint32_t)(ix + 1), cy = (uint32_t)(iy + 1), cz = (uint32_t)(iz + 1);
     if (cx > v.extent[0] + 7u || cy > v.extent[1] + 7u || cz > v.extent[2] + 7u) return 0.0f * density_scale;
     uint32_t b = ((cz >> 3) * v.cq_bc[1] + (cy >> 3)) * v.cq_bc[0] + (cx >> 3);
-    size_t o = (size_t)b * CQ_BRICK_QUADS + ((cz & 7u) * 64u + (cy & 7u) * 8u + (cx & 7u));
+    size_t o = (size_t)b * CQ_BRICK_QUADS + cq_cell(cx & 7u, cy & 7u, cz & 7u);
     float4 q0 = v.cq[o];
-    float4 q1 = v.cq[o + CQ_SLICE_QUADS];
+    float4 q1 = v.cq[o + cq_next_slice(cz)];
     v000 = q0.x; v100 = q0.y; v010 = q0.z; v110 = q0.w;
     v001 = q1.x; v101 = q1.y; v011 = q1.z; v111 = q1.w;
   } else if (LAYOUT == LAYOUT_BF) {

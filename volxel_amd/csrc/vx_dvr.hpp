@@ -172,13 +172,13 @@ __global__ __launch_bounds__(256) void render_dvr_cq(const VxParams p, const Dev
       ok[u] = eval;
       // quad index in 32 bits (24-bit multiplies; < 2^32 quads = 64 GiB), one 64-bit shift-add
       uint32_t b = mad24(mad24(cz >> 3, cby, cy >> 3), cbx, cx >> 3);
-      uint32_t cell = ((cz & 7u) << 6) | ((cy & 7u) << 3) | (cx & 7u);
+      uint32_t cell = cq_cell(cx & 7u, cy & 7u, cz & 7u);
       // unconditional loads (finished / skipped lanes read quad 0): no control flow between the
       // 2*U gathers, so they are all in flight before the first s_waitcnt
       uint32_t o = eval ? mad24(b, CQ_BRICK_QUADS, cell) : 0u;  // b < 2^24 bricks
       const float4* qp = cq + o;
       q0[u] = qp[0];
-      q1[u] = qp[CQ_SLICE_QUADS];
+      q1[u] = qp[cq_next_slice(cz)];
     }
     // ---- phase 2: interpolate, classify, composite in order -----------------------------------
 #pragma unroll
@@ -359,11 +359,11 @@ __global__ __launch_bounds__(256) void render_dvr_dp(const VxParams p, const Dev
       eval = in && !empty;
     }
     uint32_t b = mad24(mad24(cz >> 3, cby, cy >> 3), cbx, cx >> 3);
-    uint32_t cell = ((cz & 7u) << 6) | ((cy & 7u) << 3) | (cx & 7u);
+    uint32_t cell = cq_cell(cx & 7u, cy & 7u, cz & 7u);
     uint32_t o = eval ? mad24(b, CQ_BRICK_QUADS, cell) : 0u;
     const float4* qp = cq + o;
     float4 q0 = qp[0];
-    float4 q1 = qp[CQ_SLICE_QUADS];
+    float4 q1 = qp[cq_next_slice(cz)];
     float wx = 1.0f - fx, wy = 1.0f - fy, wz = 1.0f - fz;
     float lx0 = fma_(q0.y, fx, q0.x * wx);
     float lx1 = fma_(q0.w, fx, q0.z * wx);
