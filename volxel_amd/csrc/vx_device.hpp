@@ -69,12 +69,13 @@ VXD bool skip_test(const uint32_t* bits, uint32_t sh, uint32_t d0, uint32_t d1, 
 }
 
 // cell order inside an apron brick: 9 z slices of 8x8 cells; inside a slice a 128-byte line (8 quads)
-// holds 4 x 2 cells (x, y), lines x-fastest.  (Tried: 8x1 rows = the plain x-fastest order, and
+// holds 4 x 2 cells (x, y) -- in-line order x*2 + (y & 1), which costs the fewest bit operations --,
+// lines x-fastest.  (Tried: 8x1 rows = the plain x-fastest order, and
 // 2x2x2 blocks with z padded to 10 slices)
 constexpr uint32_t CQ_SLICE_QUADS = 64;
 constexpr uint32_t CQ_BRICK_QUADS = 9 * CQ_SLICE_QUADS;  // 576 float4 = 9216 B
 VXD uint32_t cq_cell(uint32_t lx, uint32_t ly, uint32_t lz) {  // local cell (0..7, 0..7, 0..8) -> quad index
-  return (lz << 6) | ((ly & 6u) << 3) | ((lx & 4u) << 1) | ((ly & 1u) << 2) | (lx & 3u);
+  return (lz << 6) | ((ly & 6u) << 3) | (lx << 1) | (ly & 1u);
 }
 VXD uint32_t cq_next_slice(uint32_t) { return CQ_SLICE_QUADS; }
 
@@ -96,6 +97,18 @@ VXD int f2i(float x) {
 VXD uint32_t mad24(uint32_t a, uint32_t b, uint32_t c) {
   uint32_t r;
   asm("v_mad_u32_u24 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(c));
+  return r;
+}
+// the same with a wave-uniform multiplier held in an SGPR (no v_mov per use)
+VXD uint32_t mad24_s(uint32_t a, uint32_t b_uniform, uint32_t c) {
+  uint32_t r;
+  asm("v_mad_u32_u24 %0, %1, %2, %3" : "=v"(r) : "v"(a), "s"(b_uniform), "v"(c));
+  return r;
+}
+// clamp to [lo, hi] in one instruction
+VXD int med3_i32(int x, int lo, int hi) {
+  int r;
+  asm("v_med3_i32 %0, %1, %2, %3" : "=v"(r) : "v"(x), "v"(lo), "v"(hi));
   return r;
 }
 

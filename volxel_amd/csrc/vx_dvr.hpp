@@ -171,54 +171,52 @@ __global__ __launch_bounds__(256) void render_dvr_cq(const VxParams p, const Dev
       }
       ok[u] = eval;
       // quad index in 32 bits (24-bit multiplies; < 2^32 quads = 64 GiB), one 64-bit shift-add
-      uint32_t b = mad24(mad24(cz >> 3, cby, cy >> 3), cbx, cx >> 3);
+      uint32_t b = mad24_s(mad24_s(cz >> 3, cby, cy >> 3), cbx, cx >> 3);
       uint32_t cell = cq_cell(cx & 7u, cy & 7u, cz & 7u);
+      uint32_t o = mad24_s(b, CQ_BRICK_QUADS, cell);  // b < 2^24 bricks
+      asm volatile("" : "+v"(o));  // keep the index math unconditional: a select, not a branch
       // unconditional loads (finished / skipped lanes read quad 0): no control flow between the
       // 2*U gathers, so they are all in flight before the first s_waitcnt
-      uint32_t o = eval ? mad24(b, CQ_BRICK_QUADS, cell) : 0u;  // b < 2^24 bricks
+      o = eval ? o : 0u;
       const float4* qp = cq + o;
       q0[u] = qp[0];
       q1[u] = qp[cq_next_slice(cz)];
     }
-    // ---- phase 2: interpolate, classify, composite in order -----------------------------------
+    // ---- phase 2: interpolate, classify, composite in order -- straight-line code: a lane that
+    // does not contribute (finished, skipped, alpha == 0, out of the sample range) runs the same
+    // instructions with alpha = 0, which leaves tau, T and C bit-for-bit unchanged
+    // (fma(0,dt,tau) == tau and its colour increment is selected to 0).
 #pragma unroll
     for (int u = 0; u < U; ++u) {
       bool a = ok[u] && alive;  // a lane that terminated earlier in this batch drops out
       unsigned long long m = __ballot(a);
       n_samples += (uint32_t)__builtin_popcountll(m);
       n_slots += m ? 64u : 0u;
-      if (a) {
-        float wx = 1.0f - fx[u], wy = 1.0f - fy[u], wz = 1.0f - fz[u];
-        float lx0 = fma_(q0[u].y, fx[u], q0[u].x * wx);
-        float lx1 = fma_(q0[u].w, fx[u], q0[u].z * wx);
-        float hx0 = fma_(q1[u].y, fx[u], q1[u].x * wx);
-        float hx1 = fma_(q1[u].w, fx[u], q1[u].z * wx);
-        float l = fma_(lx1, fy[u], lx0 * wy);
-        float h = fma_(hx1, fy[u], hx0 * wy);
-        float d = scale * fma_(h, fz[u], l * wz);
-        float dn = d * inv_maj;
-        // A7: NEAREST LUT, range test
-        int ti = (int)(dn * lenf);  // dn >= 0: truncation == floor
-        ti = ti > last ? last : ti;
-        ti = ti < 0 ? 0 : ti;
-        bool in_range = !(dn < sr0 || dn > sr1);
-        float4 rgba = tf_lds[ti];
-        float alpha = in_range ? rgba.w : 0.0f;
-        if (alpha > 0.0f) {
-          // tau += a*maj*dt; C += (T_prev - T) * rgb   (raymarch.glsl:43 / SURVEY A12)
-          tau = fma_(alpha * maj, r.dt, tau);
-          float Tn = __builtin_amdgcn_exp2f(tau * -1.4426950408889634f);
-          float dT = T - Tn;
-          Cx = fma_(dT, rgba.x, Cx);
-          Cy = fma_(dT, rgba.y, Cy);
-          Cz = fma_(dT, rgba.z, Cz);
-          T = Tn;
-          if (tau >= ert) {
-            T = 0.0f;
-            alive = false;
-          }
-        }
-      }
+      float wx = 1.0f - fx[u], wy = 1.0f - fy[u], wz = 1.0f - fz[u];
+      float lx0 = fma_(q0[u].y, fx[u], q0[u].x * wx);
+      float lx1 = fma_(q0[u].w, fx[u], q0[u].z * wx);
+      float hx0 = fma_(q1[u].y, fx[u], q1[u].x * wx);
+      float hx1 = fma_(q1[u].w, fx[u], q1[u].z * wx);
+      float l = fma_(lx1, fy[u], lx0 * wy);
+      float h = fma_(hx1, fy[u], hx0 * wy);
+      float d = scale * fma_(h, fz[u], l * wz);
+      float dn = d * inv_maj;
+      // A7: NEAREST LUT, range test
+      int ti = med3_i32((int)(dn * lenf), 0, last);  // dn >= 0: truncation == floor
+      bool in_range = !(dn < sr0 || dn > sr1);
+      float4 rgba = tf_lds[ti];
+      float alpha = (a && in_range) ? rgba.w : 0.0f;
+      bool contrib = alpha > 0.0f;
+      // tau += a*maj*dt; C += (T_prev - T) * rgb   (raymarch.glsl:43 / SURVEY A12)
+      tau = fma_(alpha * maj, r.dt, tau);
+      float Tn = __builtin_amdgcn_exp2f(tau * -1.4426950408889634f);
+      float dT = contrib ? T - Tn : 0.0f;
+      Cx = fma_(dT, rgba.x, Cx);
+      Cy = fma_(dT, rgba.y, Cy);
+      Cz = fma_(dT, rgba.z, Cz);
+      bool done = contrib && (tau >= ert);
+      T = contrib ? (done ? 0.0f : Tn) : T;
+      alive = alive && !done;
     }
     kf += (float)U;
     if (SKIP && last_empty) {

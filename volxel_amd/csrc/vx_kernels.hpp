@@ -176,7 +176,7 @@ __global__ __launch_bounds__(256) void build_cellquad(const DevVolume v, float4*
   uint32_t by = (uint32_t)((b / v.cq_bc[0]) % v.cq_bc[1]);
   uint32_t bz = (uint32_t)(b / ((uint64_t)v.cq_bc[0] * v.cq_bc[1]));
   // inverse of cq_cell
-  uint32_t lz = q >> 6, ly = (((q >> 4) & 3u) << 1) | ((q >> 2) & 1u), lx = (((q >> 3) & 1u) << 2) | (q & 3u);
+  uint32_t lz = q >> 6, ly = (((q >> 4) & 3u) << 1) | (q & 1u), lx = (q >> 1) & 7u;
   // voxel of local (l) in apron brick b: 8b - 1 + l
   int x = (int)(bx * 8u + lx) - 1, y = (int)(by * 8u + ly) - 1, z = (int)(bz * 8u + lz) - 1;
   float4 o;
