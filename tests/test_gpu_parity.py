@@ -451,6 +451,68 @@ def test_restart_from_files_end_to_end(oracle, tmp_path):
     assert np.allclose(bg[:3], 0.5, atol=1e-6)           # constant map: every background pixel is 0.5
 
 
+EDGE_CASES = {
+    # name: (image size, make_scene kwargs, transfer-function length or None for the benchmark stops)
+    "one_pixel": ((1, 1), dict(), None),
+    "ragged_7x5": ((7, 5), dict(), None),
+    "ragged_65x63": ((65, 63), dict(), None),                         # one pixel past the 64x64 shard tile
+    "ragged_130x9": ((130, 9), dict(), None),
+    "camera_inside": ((48, 40), dict(cam_pos=(0.05, 0.02, -0.1), look_at=(0.0, 0.0, 0.3)), None),
+    "empty_clip_box": ((40, 32), dict(clip_min=(0.5, 0.5, 0.5), clip_max=(0.5, 0.5, 0.5)), None),
+    "thin_clip_slab": ((40, 32), dict(clip_min=(0.0, 0.0, 0.49), clip_max=(1.0, 1.0, 0.51)), None),
+    "range_excludes_all": ((40, 32), dict(sample_range=(2.0, 3.0)), None),
+    "max_steps_10": ((40, 32), dict(dvr_max_steps=10), None),
+    "step_3_voxels": ((40, 32), dict(dvr_step_voxels=3.0), None),
+    "step_tiny": ((24, 16), dict(dvr_step_voxels=0.03125), None),
+    "ert_off": ((40, 32), dict(dvr_ert_epsilon=1e-30), None),
+    "ert_immediate": ((40, 32), dict(dvr_ert_epsilon=0.9999), None),
+    "dense": ((40, 32), dict(density_multiplier=50.0), None),
+    "tf_len_1": ((40, 32), dict(), 1),
+    "tf_len_2": ((40, 32), dict(), 2),
+    "tf_len_4096": ((40, 32), dict(), 4096),                          # past the LDS-resident LUT size
+}
+
+
+@pytest.mark.parametrize("case", sorted(EDGE_CASES))
+def test_edge_cases_match_oracle(oracle, case):
+    """ragged image sizes, degenerate clip boxes / ranges / step sizes / LUT lengths, camera inside the
+    volume, on a ragged (40x24x11 -> 64^3 padded) anisotropic volume: DVR == oracle with equal sample
+    counts for all three layouts, one stochastic mode agrees"""
+    from tests.common import make_scene, benchmark_tf, BENCH_CAM
+    (w, h), kw, tf_len = EDGE_CASES[case]
+    rng = np.random.default_rng(17)
+    vox = rng.integers(0, 4000, size=(11, 24, 40), dtype=np.uint16)
+    vox[:, :6, :] = 0
+    g = oracle.BrickGrid(vox, (0.5, 0.75, 1.25))
+    if tf_len is None:
+        tf, L = benchmark_tf()
+    else:
+        t = np.linspace(0.0, 1.0, tf_len, dtype=np.float32)
+        tf = np.stack([t, 1 - t, 0.5 + 0 * t, 0.2 + 0.8 * t], axis=1).astype(np.float32).ravel()
+        L = tf_len
+    kw = dict(kw)
+    for k, v in BENCH_CAM.items():
+        kw.setdefault(k, v)
+    kw.setdefault("sample_range", (0.05, 1.0))
+    s, cam, vol, ds, p = make_scene(g, w, h, "dvr", **kw)
+    want, oc = oracle.render(p, g, tf, L)
+    for layout in (0, 1, 2):
+        r = _renderer(g, tf, L, p, layout)
+        r.reset_counters()
+        img = _render_with_params(r, p)
+        c = r.counters()
+        assert img.shape == (h, w, 4)
+        assert np.abs(img - want).max() <= 2e-6, (case, layout)
+        assert (c.samples, c.rays, c.pixels) == (oc.samples, oc.rays, w * h), (case, layout)
+    s, cam, vol, ds, p = make_scene(g, w, h, "no_dda", **{k: v for k, v in kw.items() if not k.startswith("dvr_")})
+    want, oc = oracle.render(p, g, tf, L, frame_index=1)
+    r = _renderer(g, tf, L, p, 1)
+    img = _render_with_params(r, p, 1)
+    diff = np.abs(img - want).max(axis=2)
+    assert (diff <= 1e-4).mean() >= 0.99, (case, diff.max())
+    assert r.counters().rays == oc.rays
+
+
 def test_error_contract():
     from volxel_amd import Volxel3DRenderer, VolxelError
     r = Volxel3DRenderer(64, 64)
