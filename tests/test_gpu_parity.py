@@ -350,7 +350,7 @@ def test_low_resolution_preview_ramp(oracle):
     assert p.use_env == 1                          # the viewer's default: checkerboard map, useEnv
     want, _ = oracle.render(p, g, tf, L, frame_index=2, sample_weight=0.0, env=env)
     low = r.read_accum()
-    assert low.shape == (lh, lw, 4) and np.abs(low - want).max() <= 4e-6
+    assert low.shape == (lh, lw, 4) and np.abs(low - want).max() <= 1e-5
     disp = r.read_display()
     assert disp.shape == (64, 96, 4)
     want8, _ = oracle.blit(low, r.settings.exposure, r.settings.gamma)
@@ -364,13 +364,13 @@ def test_low_resolution_preview_ramp(oracle):
     prev = None
     for f in (5, 6):
         prev, _ = oracle.render(p, g, tf, L, frame_index=f, sample_weight=sample_weight(f), prev=prev, env=env)
-    assert np.abs(r.read_accum() - prev).max() <= 4e-6
+    assert np.abs(r.read_accum() - prev).max() <= 1e-5
     r.restart_rendering()                          # any restart drops back to the preview size
     assert (r.width, r.height, r.frame_index) == (lw, lh, 0)
     r.render(1)
     want, _ = oracle.render(compute_params(r.settings, r.camera, r.volume, r.density_scale, lw, lh,
                                            has_environment=True), g, tf, L, frame_index=0, sample_weight=0.0, env=env)
-    assert np.abs(r.read_accum() - want).max() <= 4e-6
+    assert np.abs(r.read_accum() - want).max() <= 1e-5
 
 
 def test_benchmark_runner_records(oracle):
@@ -412,7 +412,7 @@ def test_benchmark_runner_records(oracle):
     for f in (5, 6, 7):
         prev, _ = oracle.render(p, g, tf, L, frame_index=f, sample_weight=sample_weight(f), prev=prev, env=env)
     assert (r2.width, r2.height) == (fw, fh)
-    assert np.abs(r2.read_accum() - prev).max() <= 4e-6
+    assert np.abs(r2.read_accum() - prev).max() <= 1e-5
 
 
 def test_restart_from_files_end_to_end(oracle, tmp_path):
