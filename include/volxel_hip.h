@@ -162,6 +162,12 @@ int vx_upload_volume(VxContext* ctx,
                      int n_mips, const uint16_t* const* mip_data, const uint32_t (*mip_size)[3],
                      const uint32_t index_extent[3]);
 
+/* the same straight from a native brick grid (volxel_brick.h): a C / Rust host that built the grid
+ * with vxb_read_dicoms_to_grid or vxb_build_from_u16 uploads it without the copy-out of
+ * worker.ts:19-58.  The grid stays owned by the caller (vxb_free afterwards). */
+struct VxBrickGrid;
+int vx_upload_brick_grid(VxContext* ctx, const struct VxBrickGrid* grid);
+
 /* select the device layout the trilinear modes sample from (default VX_LAYOUT_CELLQUAD);
  * takes effect at the next vx_upload_volume or immediately if a volume is resident. */
 int vx_set_layout(VxContext* ctx, int layout);

@@ -513,6 +513,35 @@ def test_edge_cases_match_oracle(oracle, case):
     assert r.counters().rays == oc.rays
 
 
+def test_upload_from_native_grid_handle(oracle):
+    """vx_upload_brick_grid: builder handle -> device without the copy-out of worker.ts:19-58"""
+    from volxel_amd import Volxel3DRenderer, _abi, read_u16_stack_to_grid, synth
+    v1, sp = synth.value_noise(32, seed=1, zero_quantile=0.4)
+    v2, _ = synth.value_noise(32, seed=2, zero_quantile=0.4)
+    a = Volxel3DRenderer(64, 48)
+    a.setup_from_grid(read_u16_stack_to_grid(v1, sp))
+    a.settings.render_mode = "dvr"
+    a.render(1)
+    b = Volxel3DRenderer(64, 48)
+    b.setup_from_grid(read_u16_stack_to_grid(v2, sp))       # same extent and transform, other voxels
+    b.settings.render_mode = "dvr"
+    b.render(1)
+    assert not np.array_equal(a.read_accum(), b.read_accum())
+    lib = _abi.load_library()
+    vox = np.ascontiguousarray(v1, dtype=np.uint16)
+    g = C.c_void_p()
+    assert lib.vxb_build_from_u16(vox.ctypes.data, (C.c_uint32 * 3)(32, 32, 32), (C.c_float * 3)(*sp), 0, 2,
+                                  C.byref(g)) == 0
+    try:
+        b._check(lib.vx_upload_brick_grid(b._ctx, g))
+    finally:
+        lib.vxb_free(g)
+    b.restart_rendering()
+    b.render(1)
+    assert np.array_equal(a.read_accum(), b.read_accum())
+    assert lib.vx_upload_brick_grid(b._ctx, None) != 0 and b"null grid" in lib.vx_last_error(b._ctx)
+
+
 def test_error_contract():
     from volxel_amd import Volxel3DRenderer, VolxelError
     r = Volxel3DRenderer(64, 64)

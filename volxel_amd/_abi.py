@@ -97,6 +97,7 @@ def load_library():
         "vx_upload_volume": ([vp, vp, P(u32), vp, P(u32), vp, P(u32), i32, P(vp), vp, P(u32)], i32),
         "vx_set_layout": ([vp, i32], i32),
         "vx_upload_transfer": ([vp, vp, u32], i32),
+        "vx_upload_brick_grid": ([vp, vp], i32),
         "vx_upload_environment": ([vp, vp, u32, u32], i32),
         "vx_debug_read_importance": ([vp, vp], i32),
         "vx_set_params": ([vp, P(VxParams)], i32),

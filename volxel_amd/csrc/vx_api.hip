@@ -7,6 +7,7 @@
 #include <string>
 #include <vector>
 
+#include "../../include/volxel_brick.h"
 #include "vx_dvr.hpp"
 #include "vx_dvr_tile.hpp"
 #include "vx_kernels.hpp"
@@ -552,6 +553,25 @@ int vx_upload_volume(VxContext* c, const uint32_t* indirection, const uint32_t i
   VX_HIP(c, hipStreamSynchronize(c->stream));  // host buffers may be dropped on return
   c->has_volume = true;
   return VX_OK;
+}
+
+int vx_upload_brick_grid(VxContext* c, const VxBrickGrid* g) {
+  if (!c) return VX_ERR_INVALID;
+  if (!g) VX_FAIL(c, VX_ERR_INVALID, "vx_upload_brick_grid: null grid");
+  uint32_t is[3], rs[3], as[3], ext[3], ms[3][3];
+  vxb_indirection_size(g, is);
+  vxb_range_size(g, rs);
+  vxb_atlas_size(g, as);
+  vxb_index_extent(g, ext);
+  const uint32_t n = vxb_range_mipmaps(g);
+  if (n != 3) VX_FAIL(c, VX_ERR_INVALID, "vx_upload_brick_grid: grid has %u range mips, expected 3", n);
+  const uint16_t* mips[3];
+  for (uint32_t i = 0; i < 3; ++i) {
+    mips[i] = vxb_range_mipmap(g, i);
+    vxb_range_mipmap_stride(g, i, ms[i]);
+  }
+  return vx_upload_volume(c, vxb_indirection_data(g), is, vxb_range_data(g), rs, vxb_atlas_data(g), as, 3, mips,
+                          ms, ext);
 }
 
 int vx_set_layout(VxContext* c, int layout) {
