@@ -12,6 +12,17 @@ def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
 
 
+@pytest.fixture(scope="session", autouse=True)
+def _native_built():
+    """A fresh checkout has no built libraries (they are git-ignored): build them once per session, as
+    __graft_entry__.build() does.  hipcc cross-compiles gfx950 without a GPU."""
+    import subprocess
+    lib = os.path.join(ROOT, "volxel_amd", "libvolxel_hip.so")
+    if not os.path.exists(lib):
+        subprocess.check_call(["make", "-C", os.path.join(ROOT, "volxel_amd", "csrc"), "-s"])
+    yield
+
+
 @pytest.fixture(scope="session")
 def oracle():
     from oracle import oracle as O
