@@ -104,6 +104,27 @@ def tf_fixture():
             "benchmark": tf_table_restated(BENCHMARK_SETTINGS["transfer"]["transfer"]["colors"])}
 
 
+def brick_fixture(oracle):
+    """brick encode dumps for a 16^3 random and a 64^3 sphere volume: the three
+    textures, mips, histogram gradient and a grid of Grid::lookup values"""
+    from volxel_amd import synth
+    out = {}
+    rng = np.random.default_rng(2024)
+    for tag, vox in (("r16", rng.integers(0, 4096, size=(16, 16, 16), dtype=np.uint16)), ("s64", synth.sphere(64)[0])):
+        g = oracle.BrickGrid(vox)
+        out[tag + "_indirection"] = g.indirection
+        out[tag + "_range"] = g.range
+        out[tag + "_atlas"] = g.atlas
+        out[tag + "_atlas_size"] = np.array(g.atlas_size, dtype=np.uint32)
+        for k in range(3):
+            out[f"{tag}_mip{k}"] = g.range_mipmaps[k][0]
+        vol = oracle.make_volume(g)
+        n = vox.shape[0]
+        pts = [(x, y, z) for z in range(0, n, max(1, n // 8)) for y in range(0, n, max(1, n // 8)) for x in range(0, n, max(1, n // 8))]
+        out[tag + "_lookup"] = np.array([oracle.lib().vxo_brick_lookup(vol, x, y, z) for x, y, z in pts], dtype=np.float32)
+    return out
+
+
 ENV_KAT_U = [(0.0, 0.0), (0.5, 0.5), (0.25, 0.75), (0.999999, 0.000001), (0.6369617, 0.26978672),
              (0.04097353, 0.01652764), (0.8132702, 0.91275555), (0.123, 0.987)]
 
@@ -134,6 +155,7 @@ def main():
         print(name, img.shape, "samples", c.samples, "max", float(img[..., :3].max()))
     np.savez_compressed(os.path.join(HERE, "env_default.npz"), **env_fixture(O))
     np.savez_compressed(os.path.join(HERE, "tf_tables.npz"), **tf_fixture())
+    np.savez_compressed(os.path.join(HERE, "brick_dumps.npz"), **brick_fixture(O))
     L = O.lib()
     kat = {"tea": [], "wang": [], "xoshiro": []}
     for v0, v1 in [(0, 0), (1, 0), (0, 1), (42 * 12345, 17), (0xFFFFFFFF, 0xFFFFFFFF)]:

@@ -306,3 +306,24 @@ def test_transfer_tables_match_committed_fixture():
         assert np.array_equal(fresh[k], want[k])
     assert np.array_equal(default_transfer_function()[0], want["default"])
     assert np.array_equal(benchmark_tf()[0], want["benchmark"])
+
+
+def test_brick_dumps_fixture(native_lib, oracle):
+    """committed brick-encode dumps (16^3 random, 64^3 sphere): the oracle still produces them and the
+    native builder produces the same bytes and the same Grid::lookup values"""
+    from tests.golden.make_golden import brick_fixture
+    from volxel_amd import synth
+    want = np.load(os.path.join(os.path.dirname(__file__), "golden", "brick_dumps.npz"))
+    fresh = brick_fixture(oracle)
+    assert sorted(fresh) == sorted(want.files)
+    for k in want.files:
+        assert np.array_equal(fresh[k], want[k]), k
+    rng = np.random.default_rng(2024)
+    for tag, vox in (("r16", rng.integers(0, 4096, size=(16, 16, 16), dtype=np.uint16)), ("s64", synth.sphere(64)[0])):
+        m = read_u16_stack_to_grid(vox, (1.0, 1.0, 1.0))
+        assert np.array_equal(m.indirection, want[tag + "_indirection"])
+        assert np.array_equal(m.range, want[tag + "_range"])
+        assert np.array_equal(m.atlas, want[tag + "_atlas"])
+        assert tuple(m.atlas_size) == tuple(want[tag + "_atlas_size"])
+        for k in range(3):
+            assert np.array_equal(m.range_mipmaps[k][0], want[f"{tag}_mip{k}"])
