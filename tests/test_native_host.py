@@ -327,3 +327,53 @@ def test_brick_dumps_fixture(native_lib, oracle):
         assert tuple(m.atlas_size) == tuple(want[tag + "_atlas_size"])
         for k in range(3):
             assert np.array_equal(m.range_mipmaps[k][0], want[f"{tag}_mip{k}"])
+
+
+def test_headers_are_plain_c_and_link(native_lib, tmp_path):
+    """a C99 host: both headers compile with -pedantic, the program links against libvolxel_hip.so, builds
+    a brick grid from DICOM-free input, and gets the no-device error from vx_create on this box"""
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    src = r'''
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+#include "volxel_hip.h"
+#include "volxel_brick.h"
+int main(void) {
+  uint16_t* vox = (uint16_t*)calloc(16 * 16 * 16, 2);
+  for (int i = 0; i < 16 * 16 * 16; ++i) vox[i] = (uint16_t)(i % 977);
+  uint32_t dims[3] = {16, 16, 16};
+  float sp[3] = {1.f, 1.f, 2.f};
+  VxBrickGrid* g = NULL;
+  if (vxb_build_from_u16(vox, dims, sp, 0, 1, &g) != VXB_OK) { printf("build: %s\n", vxb_last_error()); return 1; }
+  uint32_t ext[3];
+  float t[16];
+  vxb_index_extent(g, ext);
+  vxb_transform(g, t);
+  printf("extent %u %u %u scale_z %g bricks %u lookup %.6f\n", ext[0], ext[1], ext[2], t[10], vxb_brick_counter(g),
+         vxb_lookup(g, 3, 2, 1));
+  VxParams p;
+  memset(&p, 0, sizeof p);
+  printf("sizeof(VxParams) %u version %s\n", (unsigned)sizeof p, vx_version());
+  VxContext* c = NULL;
+  int rc = vx_create(0, &c);
+  if (rc == VX_OK) {            /* a GPU box: upload straight from the handle */
+    rc = vx_upload_brick_grid(c, g);
+    printf("gpu upload rc %d\n", rc);
+    vx_destroy(c);
+  } else {
+    printf("create rc %d: %s\n", rc, vx_last_error(NULL));
+  }
+  vxb_free(g);
+  free(vox);
+  return 0;
+}
+'''
+    (tmp_path / "host.c").write_text(src)
+    exe = str(tmp_path / "host")
+    subprocess.check_call(["gcc", "-std=c99", "-pedantic", "-Wall", "-Werror", "-I", os.path.join(root, "include"),
+                           str(tmp_path / "host.c"), "-o", exe, "-L", os.path.join(root, "volxel_amd"), "-lvolxel_hip",
+                           "-Wl,-rpath," + os.path.join(root, "volxel_amd")])
+    out = subprocess.check_output([exe], timeout=120).decode()
+    assert "extent 64 64 64 scale_z 2" in out and "sizeof(VxParams) %d" % C.sizeof(_abi.VxParams) in out
+    assert "gpu upload rc 0" in out or "no HIP device" in out
