@@ -83,6 +83,7 @@ def test_node_host_renders_like_the_oracle(oracle, tmp_path):
                                                       for m in ("default", "no_dda", "raymarch")]}
     json.dump(coll, open(tmp_path / "bench.json", "w"))
     _run(tmp_path, "gpu", str(tmp_path / "bench.json"))
+    assert json.load(open(tmp_path / "pipelined.json")) == {"same": True, "frameIndex": 13}
     res = json.load(open(tmp_path / "benchmark_results.json"))
     assert [x["name"] for x in res] == ["default", "no_dda", "raymarch"]
     for x in res:                                                     # frames 0..6

@@ -34,7 +34,7 @@ export declare class Volxel3DDicomRenderer {
   /** data-benchmark-url runner (viewer.ts:856-890); returns VolxelBenchmarkResult records */
   startBenchmark(collection: { sharedSettings: any[]; benchmarks: any[] }, volumes?: Record<string, BrickGridMessage>): any[];
   bindUniforms(): { buffer: ArrayBuffer };
-  render(frames?: number): void;
+  render(frames?: number, inFlight?: number): void;
   finish(): void;
   readAccum(): Float32Array;
   readDisplay(): Uint8Array;

@@ -38,6 +38,13 @@ if (process.argv[3] === 'gpu') {
   fs.writeFileSync(path.join(out, 'accum.bin'), Buffer.from(r.readAccum().buffer));
   fs.writeFileSync(path.join(out, 'params.bin'), Buffer.from(r.params.buffer));
   fs.writeFileSync(path.join(out, 'counters.json'), JSON.stringify(r.counters()));
+  { // 12 more frames one by one vs the same frames 8 per launch: identical accumulators
+    r.render(12); const a = r.readAccum().slice();
+    r.restartRendering(); r.render(1); r.render(12, 8); const b = r.readAccum();
+    let same = a.length === b.length;
+    for (let i = 0; same && i < a.length; ++i) same = a[i] === b[i];
+    fs.writeFileSync(path.join(out, 'pipelined.json'), JSON.stringify({ same, frameIndex: r.frameIndex }));
+  }
   if (process.argv[4]) { // benchmark collection JSON -> result records (viewer.ts:856-890)
     const coll = JSON.parse(fs.readFileSync(process.argv[4], 'utf8'));
     fs.writeFileSync(path.join(out, 'benchmark_results.json'), JSON.stringify(r.startBenchmark(coll)));

@@ -292,17 +292,28 @@ class Volxel3DDicomRenderer {
     return p;
   }
 
-  render(frames = 1) { // viewer.ts:1183-1293
+  /** frames accumulation samples; inFlight > 1 renders that many per launch (same bits, vx_render_frames) */
+  render(frames = 1, inFlight = 1) { // viewer.ts:1183-1293
+    const weight = f => (f < LOW_RES_DURATION ? 0 : (f - LOW_RES_DURATION) / (f - LOW_RES_DURATION + 1)); // viewer.ts:1356
     let bound = false;
-    for (let i = 0; i < frames && this.frameIndex <= this.settings.maxSamples; ++i) {
+    for (let i = 0; i < frames && this.frameIndex <= this.settings.maxSamples;) {
       if (this.lowResPreview && this.frameIndex >= LOW_RES_DURATION && this.resolutionFactor !== 1.0) {
         this.resolutionFactor = 1.0; this.resizeFramebuffersToCanvas(); bound = false; // viewer.ts:1185-1188
       }
       if (!bound) { this.bindUniforms(); bound = true; }
       const f = this.frameIndex;
-      const w = f < LOW_RES_DURATION ? 0 : (f - LOW_RES_DURATION) / (f - LOW_RES_DURATION + 1); // viewer.ts:1356
-      native.renderFrame(this.ctx, f, w);
-      this.frameIndex++;
+      const ramp = this.lowResPreview && f < LOW_RES_DURATION;   // the size changes at LOW_RES_DURATION
+      let n = Math.min(frames - i, this.settings.maxSamples + 1 - f);
+      if (ramp) n = Math.min(n, LOW_RES_DURATION - f);
+      if (inFlight > 1 && n > 1) {
+        const w = new Float32Array(n);
+        for (let k = 0; k < n; ++k) w[k] = weight(f + k);
+        native.renderFrames(this.ctx, f, w, inFlight);
+      } else {
+        n = 1;
+        native.renderFrame(this.ctx, f, weight(f));
+      }
+      this.frameIndex += n; i += n;
     }
   }
   /** startBenchmark (viewer.ts:856-890) + the result record of viewer.ts:1229-1241.  `volumes` maps an

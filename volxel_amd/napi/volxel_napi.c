@@ -232,6 +232,25 @@ static napi_value n_render_frame(napi_env env, napi_callback_info info) {
   return NULL;
 }
 
+/* renderFrames(ctx, firstFrame, Float32Array weights, inFlight): weights.length accumulation frames,
+ * up to inFlight of them per launch (vx_render_frames) */
+static napi_value n_render_frames(napi_env env, napi_callback_info info) {
+  napi_value a[4];
+  if (!get_args(env, info, 4, a)) return NULL;
+  VxContext* c = get_ctx(env, a[0]);
+  if (!c) return NULL;
+  uint32_t f;
+  int32_t in_flight;
+  void* w;
+  size_t n;
+  NAPI_OK(napi_get_value_uint32(env, a[1], &f));
+  if (!typed(env, a[2], napi_float32_array, &w, &n)) return NULL;
+  NAPI_OK(napi_get_value_int32(env, a[3], &in_flight));
+  if (n > 0xffffffffu) return throw_msg(env, "renderFrames: too many frames");
+  if (vx_render_frames(c, f, (uint32_t)n, (const float*)w, in_flight) != VX_OK) return throw_msg(env, vx_last_error(c));
+  return NULL;
+}
+
 static napi_value n_finish(napi_env env, napi_callback_info info) {
   napi_value a[1];
   if (!get_args(env, info, 1, a)) return NULL;
@@ -474,7 +493,7 @@ static napi_value init(napi_env env, napi_value exports) {
   static const struct { const char* name; napi_callback fn; } fns[] = {
       {"create", n_create}, {"destroy", n_destroy}, {"uploadVolume", n_upload_volume},
       {"uploadTransfer", n_upload_transfer}, {"uploadEnvironment", n_upload_environment}, {"setParams", n_set_params}, {"sizeofParams", n_sizeof_params},
-      {"resize", n_resize}, {"setLayout", n_set_layout}, {"renderFrame", n_render_frame}, {"finish", n_finish},
+      {"resize", n_resize}, {"setLayout", n_set_layout}, {"renderFrame", n_render_frame}, {"renderFrames", n_render_frames}, {"finish", n_finish},
       {"readAccum", n_read_accum}, {"readDisplay", n_read_display},
       {"readDisplayScaled", n_read_display_scaled}, {"getCounters", n_get_counters},
       {"resetCounters", n_reset_counters}, {"version", n_version}, {"buildBrickGrid", n_build_brick_grid},
