@@ -1,4 +1,5 @@
-"""Independent NumPy restatement of RNG, brick codec and the DVR loop.  TEST INFRASTRUCTURE.
+"""Independent NumPy restatement of RNG, brick codec, the DVR loop and -- pixel by pixel -- the three
+reference render modes with trace_path (path_pixel).  TEST INFRASTRUCTURE.
 
 Second implementation written against the reference text (not against vx_oracle.c) so that
 the two can pin each other -- the reference itself ships no vectors (PARITY UNPINNED).
@@ -270,3 +271,331 @@ def dvr_image(p, grid, tf, L, max_iter=100000):
         out[..., c] = Lc
     out[..., 3] = 1
     return out, samples
+
+
+# ---- the path tracer for one pixel, NO_DDA mode (fragment.frag main + trace_path, ---------------
+# ---- sampling/normal.glsl, environment.glsl directional branch), scalar Python -------------------
+def _f(x):
+    return F32(x)
+
+
+def _dot(a, b):  # dot as an fma chain
+    return fma(a[2], b[2], fma(a[1], b[1], a[0] * b[0]))
+
+
+def _normalize(a):
+    inv = _f(1) / np.sqrt(_dot(a, a))
+    return [x * inv for x in a]
+
+
+def _slab(o, d, lo, hi):  # utils.glsl:61-69
+    with np.errstate(divide="ignore", invalid="ignore"):
+        inv = [_f(1) / x for x in d]
+        a = [(_f(lo[i]) - o[i]) * inv[i] for i in range(3)]
+        b = [(_f(hi[i]) - o[i]) * inv[i] for i in range(3)]
+    mn = lambda x, y: y if y < x else x
+    mx = lambda x, y: y if x < y else x
+    tmin = [mn(x, y) for x, y in zip(a, b)]
+    tmax = [mx(x, y) for x, y in zip(a, b)]
+    near = mx(_f(0), mx(tmin[0], mx(tmin[1], tmin[2])))
+    far = mn(tmax[0], mn(tmax[1], tmax[2]))
+    return bool(near <= far), near, far
+
+
+def _logf(x):
+    return _f(np.log(np.float64(x)))
+
+
+def path_pixel(p, grid, tf, L, px, py, frame):
+    """One pixel of fragment.frag:128-158 with u_sample_weight = 0 for the three reference render modes
+    (p.render_mode 0 default/DDA, 1 no_dda, 2 raymarch), directional light (u_use_env = 0).
+    Returns (rgba, number of volume samples)."""
+    assert p.use_env == 0 and p.debug_hits == 0 and p.render_mode in (0, 1, 2)
+    vol = NpVolume(grid)
+    # range texture levels 0..3 (.x = R = max), brick.rs:19-23,153-190
+    levels = [(np.asarray(grid.range, dtype=np.uint16).reshape(-1, 2)[:, 0].view(np.float16).astype(F32),
+               tuple(grid.indirection_size))]
+    for m, st in grid.range_mipmaps:
+        levels.append((np.asarray(m, dtype=np.uint16).reshape(-1, 2)[:, 0].view(np.float16).astype(F32), tuple(st)))
+    W, H = p.res[0], p.res[1]
+    rs = Xoshiro(pixel_seed(px, py, W, frame))
+    rng = lambda: _f(rs.rng())
+    n_samples = 0
+    # fragment.frag:146 + :57-65 setup_world_ray(tex, (rng2 + rng2) / 2)
+    a0, a1, b0, b1 = rng(), rng(), rng(), rng()
+    jx, jy = (a0 + b0) / _f(2), (a1 + b1) / _f(2)
+    tex = [(_f(px) + _f(0.5)) / _f(W), (_f(py) + _f(0.5)) / _f(H)]
+    off = [fma(jx, _f(2), _f(-1)) * (_f(1) / _f(W)), fma(jy, _f(2), _f(-1)) * (_f(1) / _f(H))]
+    sx, sy = tex[0] + off[0], tex[1] + off[1]
+    one, zero = _f(1), _f(0)
+    cw = _mat_mul(p.camera_view_inv[:], zero, zero, zero, one)
+    cam = [cw[i] / cw[3] for i in range(3)]
+    vp = _mat_mul(p.camera_proj_inv[:], fma(sx, _f(2), _f(-1)), fma(sy, _f(2), _f(-1)), zero, one)
+    vv = [vp[i] / vp[3] for i in range(3)]
+    wp = _mat_mul(p.camera_view_inv[:], vv[0], vv[1], vv[2], one)
+    o = cam
+    d = _normalize([wp[i] / wp[3] - cam[i] for i in range(3)])
+    lo, hi = p.volume_aabb_min, p.volume_aabb_max
+    inv_maj, maj = _f(p.volume_inv_maj), _f(p.volume_maj)
+    albedo = [_f(p.volume_albedo[i]) for i in range(3)]
+    g = _f(p.volume_phase_g)
+    inv_4pi = _f(1) / (_f(4) * _f(np.pi))
+
+    def to_index(o, d):
+        ip = _mat_mul(p.density_transform_inv[:], o[0], o[1], o[2], one)
+        idr = _mat_mul(p.density_transform_inv[:], d[0], d[1], d[2], zero)
+        return ip[:3], idr[:3]
+
+    def lookup(ip, idr, t):
+        nonlocal n_samples
+        n_samples += 1
+        pos = [fma(t, idr[i], ip[i]) for i in range(3)]
+        dens = vol.trilinear(p.volume_density_scale, *pos)
+        return transfer(tf, L, p.sample_range, np.asarray(dens * inv_maj))
+
+    def rnd_half_away(x):  # GLSL round(); halves go away from zero (quirk Q12)
+        return int(np.floor(np.float64(x) + 0.5)) if x >= 0 else -int(np.floor(-np.float64(x) + 0.5))
+
+    def lookup_tf(dn):
+        return transfer(tf, L, p.sample_range, np.asarray(dn))
+
+    def majorant_at(curr, mip):  # common.glsl:50-53, then the extinction of that density (dda.glsl:38)
+        sh = 3 + mip
+        b = [int(np.floor(c)) >> sh for c in curr]
+        data, (sx, sy, sz) = levels[mip]
+        r = zero
+        if 0 <= b[0] < sx and 0 <= b[1] < sy and 0 <= b[2] < sz:
+            r = data[(b[2] * sy + b[1]) * sx + b[0]]
+        m = _f(p.volume_density_scale) * r
+        return maj * lookup_tf(m * inv_maj)[3]
+
+    def step_dda(pos, inv_dir, mip):  # dda.glsl:11-16
+        dim = _f(8 << mip)
+        inv_dim = one / dim
+        out = []
+        for c in range(3):
+            off = dim + _f(0.5) if inv_dir[c] >= 0 else _f(-0.5)
+            out.append(((np.floor(pos[c] * inv_dim) * dim + off) - pos[c]) * inv_dir[c])
+        mn = lambda x, y: y if y < x else x
+        return mn(out[0], mn(out[1], out[2]))
+
+    def density_stochastic(pos):  # common.glsl:9-32,72-76
+        nonlocal n_samples
+        n_samples += 1
+        q = [c - _f(0.5) for c in pos]
+        ii = [int(np.floor(c)) for c in q]
+        t = [q[c] - _f(ii[c]) for c in range(3)]
+        t2 = [x * x for x in t]
+        sixth = one / _f(6)
+        idx = [0, 0, 0]
+        w = [sixth * (fma(_f(-3), t[c], fma(_f(3), t2[c], -t[c] * t2[c])) + one) for c in range(3)]
+        sw = list(w)
+        taps = (lambda c: sixth * (fma(_f(-6), t2[c], _f(3) * t[c] * t2[c]) + _f(4)),
+                lambda c: sixth * (fma(_f(3), t[c], fma(_f(3), t2[c], _f(-3) * t[c] * t2[c])) + one),
+                lambda c: sixth * t[c] * t2[c])
+        for k, wf in enumerate(taps):
+            w = [wf(c) for c in range(3)]
+            sw = [w[c] + sw[c] for c in range(3)]
+            r = [rng(), rng(), rng()]
+            for c in range(3):
+                den = sw[c] if _f(1e-3) < sw[c] else _f(1e-3)
+                if r[c] < w[c] / den:
+                    idx[c] = k + 1
+        tap = [ii[c] + idx[c] - 1 for c in range(3)]
+        return _f(p.volume_density_scale) * vol.brick(tap[0], tap[1], tap[2])
+
+    def sample_raymarch(o, d, thr):  # raymarch.glsl:25-55
+        hit, near, far = _slab(o, d, lo, hi)
+        if not hit:
+            return False, zero
+        ip, idr = to_index(o, d)
+        tau_target = -_logf(one - rng())
+        dt = (far - near) / _f(64)
+        near = fma(rng(), dt, near)
+        tau, t = zero, zero
+        for i in range(64):
+            tt = fma(_f(i), dt, near)
+            t = far if far < tt else tt
+            dens = density_stochastic([fma(t, idr[c], ip[c]) for c in range(3)])
+            rgba = lookup_tf(dens * inv_maj)
+            tau = fma(rgba[3] * maj, dt, tau)
+            if tau >= tau_target:
+                for c in range(3):
+                    thr[c] = thr[c] * (rgba[c] * albedo[c])
+                return True, t
+        return False, t
+
+    def transmittance_raymarch(o, d):  # raymarch.glsl:8-23
+        hit, near, far = _slab(o, d, lo, hi)
+        if not hit:
+            return one
+        ip, idr = to_index(o, d)
+        dt = (far - near) / _f(64)
+        near = fma(rng(), dt, near)
+        tau = zero
+        for i in range(64):
+            tt = fma(_f(i), dt, near)
+            t = far if far < tt else tt
+            dens = density_stochastic([fma(t, idr[c], ip[c]) for c in range(3)])
+            tau = fma(lookup_tf(dens * inv_maj)[3] * maj, dt, tau)
+        return _f(np.exp(-np.float64(tau)))
+
+    def dda_walk(o, d, shadow, thr):  # dda.glsl:21-62 (shadow) / :65-98 (primary)
+        hit, near, far = _slab(o, d, lo, hi)
+        if not hit:
+            return (one if shadow else False), zero
+        ip, idr = to_index(o, d)
+        with np.errstate(divide="ignore"):
+            ri = [one / x for x in idr]
+        t = near + _f(1e-6)
+        tr, tau, mip, step = one, -_logf(one - rng()), _f(3), 0
+        while t < far and (not shadow or step < 100):
+            step += 1
+            curr = [fma(t, idr[c], ip[c]) for c in range(3)]
+            m = rnd_half_away(mip)
+            majorant = majorant_at(curr, m)
+            dt = step_dda(curr, ri, m)
+            t = t + dt
+            tau = fma(-majorant, dt, tau)
+            mip = mip + _f(0.25) if mip + _f(0.25) < _f(3) else _f(3)
+            if tau > 0:
+                continue
+            with np.errstate(divide="ignore", invalid="ignore"):
+                t = t + tau / majorant
+            if t >= far:
+                break
+            rgba = lookup(ip, idr, t)
+            dd = maj * rgba[3]
+            if rng() * majorant < dd:
+                if not shadow:
+                    for c in range(3):
+                        thr[c] = (thr[c] * albedo[c]) * rgba[c]
+                    return True, t
+                with np.errstate(divide="ignore", invalid="ignore"):
+                    f = one - maj / majorant
+                tr = tr * (f if zero < f else zero)
+                if tr < _f(0.1):
+                    prob = one - tr
+                    if rng() < prob:
+                        return zero, t
+                    tr = tr / (one - prob)
+            tau = -_logf(one - rng())
+            mip = mip - _f(2) if zero < mip - _f(2) else zero
+        return (tr if shadow else False), t
+
+    def sample_volume(o, d, thr):
+        if p.render_mode == 2:
+            return sample_raymarch(o, d, thr)
+        if p.render_mode == 0:
+            return dda_walk(o, d, False, thr)
+        return sample_simple(o, d, thr)
+
+    def transmittance(o, d):
+        if p.render_mode == 2:
+            return transmittance_raymarch(o, d)
+        if p.render_mode == 0:
+            return dda_walk(o, d, True, None)[0]
+        return transmittance_simple(o, d)
+
+    def sample_simple(o, d, thr):  # normal.glsl:33-57
+        hit, near, far = _slab(o, d, lo, hi)
+        if not hit:
+            return False, zero
+        ip, idr = to_index(o, d)
+        t = fma(-_logf(one - rng()), inv_maj, near)
+        while t < far:
+            rgba = lookup(ip, idr, t)
+            p_real = (maj * rgba[3]) * inv_maj
+            if rng() < p_real:
+                for c in range(3):
+                    thr[c] = thr[c] * (rgba[c] * albedo[c])
+                return True, t
+            t = fma(-_logf(one - rng()), inv_maj, t)
+        return False, t
+
+    def transmittance_simple(o, d):  # normal.glsl:6-31
+        hit, near, far = _slab(o, d, lo, hi)
+        if not hit:
+            return one
+        ip, idr = to_index(o, d)
+        t = fma(-_logf(one - rng()), inv_maj, near)
+        tr = one
+        while t < far:
+            rgba = lookup(ip, idr, t)
+            dd = maj * rgba[3]
+            tr = tr * fma(-dd, inv_maj, one)
+            if tr < _f(0.1):
+                prob = one - tr
+                if rng() < prob:
+                    return zero
+                tr = tr / (one - prob)
+            t = fma(-_logf(one - rng()), inv_maj, t)
+        return tr
+
+    def phase_hg(cos_t):  # utils.glsl:121-124
+        denom = fma(_f(2) * g, cos_t, one + g * g)
+        return inv_4pi * (one - g * g) / (denom * np.sqrt(denom))
+
+    def lookup_env(dr):  # environment.glsl:19-22 with the pow base clamped at 0 (quirk Q16)
+        nl = [-_f(p.light_dir[i]) for i in range(3)]
+        c = _dot(dr, nl)
+        c = c if c > 0 else zero
+        s = _f(min(max(float(np.float64(c) ** 300.0), 0.0), 1.0))
+        e = _f(p.env_strength) * fma(s, _f(4), _f(0.01))
+        return [e, e, e]
+
+    # trace_path, fragment.frag:79-124
+    Lr, thr = [zero, zero, zero], [one, one, one]
+    free_path, n_paths, f_p = True, 0, zero
+    while True:
+        hit, t = sample_volume(o, d, thr)
+        if not hit:
+            break
+        o = [fma(t, d[i], o[i]) for i in range(3)]
+        rng(); rng()                                          # rng2 handed to sample_environment
+        w_i = [-_f(p.light_dir[i]) for i in range(3)]
+        le, pdf = _f(p.env_strength) * _f(4.01), one
+        f_p = phase_hg(_dot([-x for x in d], w_i))
+        mis = (pdf * pdf) / (pdf * pdf + f_p * f_p) if p.show_environment > 0 else one
+        tr = transmittance(o, w_i)
+        for c in range(3):
+            Lr[c] = Lr[c] + thr[c] * mis * f_p * tr * le / pdf
+        n_paths += 1
+        if n_paths >= p.bounces:
+            free_path = False
+            break
+        rr = _dot(thr, [_f(0.212671), _f(0.715160), _f(0.072169)])
+        if rr < _f(0.1):
+            prob = one - rr
+            if rng() < prob:
+                free_path = False
+                break
+            thr = [x / (one - prob) for x in thr]
+        u0, u1 = rng(), rng()
+        if abs(g) < _f(1e-4):
+            cos_t = fma(_f(-2), u0, one)
+        else:
+            q = (one - g * g) / fma(_f(2) * g, u0, one - g)
+            cos_t = ((one + g * g) - q * q) / (_f(2) * g)
+        sin_t = np.sqrt(max(zero, one - cos_t * cos_t))
+        phi = _f(2) * _f(np.pi) * u1
+        v = [sin_t * _f(np.cos(np.float64(phi))), sin_t * _f(np.sin(np.float64(phi))), cos_t]
+        N = d
+        if abs(N[0]) > abs(N[1]):
+            ln = np.sqrt(fma(N[2], N[2], N[0] * N[0]))
+            T = [-N[2] / ln, zero / ln, N[0] / ln]
+        else:
+            ln = np.sqrt(fma(N[2], N[2], N[1] * N[1]))
+            T = [zero / ln, N[2] / ln, -N[1] / ln]
+        B = [fma(N[1], T[2], -(N[2] * T[1])), fma(N[2], T[0], -(N[0] * T[2])), fma(N[0], T[1], -(N[1] * T[0]))]
+        sd = _normalize([fma(v[2], N[i], fma(v[1], B[i], v[0] * T[i])) for i in range(3)])
+        f_p = phase_hg(_dot([-x for x in d], sd))
+        d = sd
+    if free_path and p.show_environment > 0:
+        le = lookup_env(d)
+        with np.errstate(invalid="ignore", divide="ignore"):
+            mis = (f_p * f_p) / (f_p * f_p + zero) if n_paths > 0 else one
+        for c in range(3):
+            Lr[c] = fma(thr[c] * mis, le[c], Lr[c])
+    out = [x if np.isfinite(x) else zero for x in Lr]       # sanitize, utils.glsl:96-98
+    return np.array(out + [one], dtype=F32), n_samples

@@ -10,7 +10,8 @@
  * in the build image.  This file is a from-scratch scalar restatement that follows the
  * cited reference lines; the only available "pins" are the canonical TEA / Wang-hash /
  * IEEE binary16 definitions and agreement with the independent NumPy restatement in
- * oracle/np_oracle.py.
+ * oracle/np_oracle.py (RNG, brick codec, trilinear, DVR, and the three reference render modes with
+ * trace_path pixel by pixel: bit-identical on the test scenes).
  */
 #ifndef VX_ORACLE_H
 #define VX_ORACLE_H
