@@ -306,11 +306,12 @@ def _logf(x):
     return _f(np.log(np.float64(x)))
 
 
-def path_pixel(p, grid, tf, L, px, py, frame):
+def path_pixel(p, grid, tf, L, px, py, frame, env=None):
     """One pixel of fragment.frag:128-158 with u_sample_weight = 0 for the three reference render modes
-    (p.render_mode 0 default/DDA, 1 no_dda, 2 raymarch), directional light (u_use_env = 0).
+    (p.render_mode 0 default/DDA, 1 no_dda, 2 raymarch); directional light, or -- with u_use_env = 1 --
+    env = (texture [H,W,4] in GL row order, [importance level 0 .. 9]) as environment.ts builds them.
     Returns (rgba, number of volume samples)."""
-    assert p.use_env == 0 and p.debug_hits == 0 and p.render_mode in (0, 1, 2)
+    assert p.debug_hits == 0 and p.render_mode in (0, 1, 2) and (p.use_env == 0 or env is not None)
     vol = NpVolume(grid)
     # range texture levels 0..3 (.x = R = max), brick.rs:19-23,153-190
     levels = [(np.asarray(grid.range, dtype=np.uint16).reshape(-1, 2)[:, 0].view(np.float16).astype(F32),
@@ -536,7 +537,61 @@ def path_pixel(p, grid, tf, L, px, py, frame):
         denom = fma(_f(2) * g, cos_t, one + g * g)
         return inv_4pi * (one - g * g) / (denom * np.sqrt(denom))
 
+    def env_texture(u, v):  # texture(u_envmap, uv): LINEAR, REPEAT s, CLAMP_TO_EDGE t, exact fp32 weights
+        tex = env[0]
+        h, w = tex.shape[:2]
+        x, y = fma(u, _f(w), _f(-0.5)), fma(v, _f(h), _f(-0.5))
+        fx, fy = np.floor(x), np.floor(y)
+        a, b = x - fx, y - fy
+        i0, j0 = int(fx), int(fy)
+        i1, j1 = (i0 + 1) % w, min(max(j0 + 1, 0), h - 1)
+        i0, j0 = i0 % w, min(max(j0, 0), h - 1)
+        mix = lambda p0, p1, t: fma(p1, t, p0 * (one - t))
+        return [mix(mix(tex[j0, i0, c], tex[j0, i1, c], a), mix(tex[j1, i0, c], tex[j1, i1, c], a), b) for c in range(3)]
+
+    def imp(x, y, mip):
+        lv = env[1][mip]
+        n = lv.shape[0]
+        return lv[y, x] if 0 <= x < n and 0 <= y < n else zero
+
+    def sample_env(u0, u1):  # environment.glsl:35-79
+        pxl, pyl, sx_, sy_ = 0, 0, u0, u1
+        for mip in range(8, -1, -1):
+            pxl, pyl = pxl * 2, pyl * 2
+            w = [imp(pxl, pyl, mip), imp(pxl + 1, pyl, mip), imp(pxl, pyl + 1, mip), imp(pxl + 1, pyl + 1, mip)]
+            q = [w[0] + w[2], w[1] + w[3]]
+            with np.errstate(divide="ignore", invalid="ignore"):
+                den = q[0] + q[1]
+                dd = q[0] / (den if _f(1e-8) < den else _f(1e-8))
+                if sx_ < dd:
+                    offx, sx_ = 0, sx_ / dd
+                else:
+                    offx, sx_ = 1, (sx_ - dd) / (one - dd)
+                pxl += offx
+                e = w[offx] / q[offx]
+                if sy_ < e:
+                    sy_ = sy_ / e
+                else:
+                    pyl, sy_ = pyl + 1, (sy_ - e) / (one - e)
+        inv_dim = one / _f(512)
+        uvx, uvy = (_f(pxl) + sx_) * inv_dim, (_f(pyl) + sy_) * inv_dim
+        clamp01 = lambda x: min(max(x, zero), one)
+        theta = clamp01(one - uvy) * _f(np.pi)
+        phi = (clamp01(uvx) * _f(2) - one) * _f(np.pi)
+        sin_t = _f(np.sin(np.float64(theta)))
+        wi = [sin_t * _f(np.cos(np.float64(phi))), _f(np.cos(np.float64(theta))), sin_t * _f(np.sin(np.float64(phi)))]
+        t = env_texture(uvx, uvy)
+        pdf = imp(pxl, pyl, 0) / imp(0, 0, 9)
+        return wi, [_f(p.env_strength) * c for c in t], pdf * inv_4pi
+
+    def lookup_env_map(dr):  # environment.glsl:23-26
+        u = _f(np.arctan2(np.float64(dr[2]), np.float64(dr[0]))) / (_f(2) * _f(np.pi)) + _f(0.5)
+        v = one - _f(np.arccos(np.float64(dr[1]))) / _f(np.pi)
+        return [_f(p.env_strength) * c for c in env_texture(u, v)]
+
     def lookup_env(dr):  # environment.glsl:19-22 with the pow base clamped at 0 (quirk Q16)
+        if p.use_env > 0:
+            return lookup_env_map(dr)
         nl = [-_f(p.light_dir[i]) for i in range(3)]
         c = _dot(dr, nl)
         c = c if c > 0 else zero
@@ -552,14 +607,17 @@ def path_pixel(p, grid, tf, L, px, py, frame):
         if not hit:
             break
         o = [fma(t, d[i], o[i]) for i in range(3)]
-        rng(); rng()                                          # rng2 handed to sample_environment
+        e0, e1 = rng(), rng()                                 # rng2 handed to sample_environment
         w_i = [-_f(p.light_dir[i]) for i in range(3)]
-        le, pdf = _f(p.env_strength) * _f(4.01), one
-        f_p = phase_hg(_dot([-x for x in d], w_i))
-        mis = (pdf * pdf) / (pdf * pdf + f_p * f_p) if p.show_environment > 0 else one
-        tr = transmittance(o, w_i)
-        for c in range(3):
-            Lr[c] = Lr[c] + thr[c] * mis * f_p * tr * le / pdf
+        le3, pdf = [_f(p.env_strength) * _f(4.01)] * 3, one
+        if p.use_env > 0:
+            w_i, le3, pdf = sample_env(e0, e1)
+        if pdf > 0:
+            f_p = phase_hg(_dot([-x for x in d], w_i))
+            mis = (pdf * pdf) / (pdf * pdf + f_p * f_p) if p.show_environment > 0 else one
+            tr = transmittance(o, w_i)
+            for c in range(3):
+                Lr[c] = Lr[c] + thr[c] * mis * f_p * tr * le3[c] / pdf
         n_paths += 1
         if n_paths >= p.bounces:
             free_path = False
@@ -593,8 +651,11 @@ def path_pixel(p, grid, tf, L, px, py, frame):
         d = sd
     if free_path and p.show_environment > 0:
         le = lookup_env(d)
+        pe = zero
+        if p.use_env > 0:  # environment.glsl:82-86
+            pe = _dot(le, [_f(0.212671), _f(0.715160), _f(0.072169)]) / imp(0, 0, 9) * inv_4pi
         with np.errstate(invalid="ignore", divide="ignore"):
-            mis = (f_p * f_p) / (f_p * f_p + zero) if n_paths > 0 else one
+            mis = (f_p * f_p) / (f_p * f_p + pe * pe) if n_paths > 0 else one
         for c in range(3):
             Lr[c] = fma(thr[c] * mis, le[c], Lr[c])
     out = [x if np.isfinite(x) else zero for x in Lr]       # sanitize, utils.glsl:96-98
