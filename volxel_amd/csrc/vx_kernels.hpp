@@ -86,9 +86,18 @@ VXD void flush_counts(DevCounters* dc, const Counts& c, uint32_t pixels) {
 
 constexpr uint32_t TF_LDS_MAX = 2048;  // entries staged in LDS (32 KiB); longer LUTs stay in L1/L2
 
+// Occupancy the register allocator is asked for, per mode.  The path-traced modes are bound by latency and
+// divergence (about 37 % of the lane slots of an issued VALU instruction do work), so more resident waves
+// pay even at the price of a few spills: measured on config 3 (tools/variant_modes.sh, ms per frame, free /
+// 6 / 8 waves per SIMD): default 0.825 / 0.755 / 0.697, default with 3 bounces 2.54 / 2.30 / 2.04, no_dda
+// 0.986 / 0.925 / 0.954, raymarch 1.22 / 1.24 / 1.25, dvr_phong 1.03 / 1.03 / 0.97.
+constexpr int generic_min_waves(int mode) {
+  return mode == VX_MODE_DEFAULT || mode == VX_MODE_DVR_PHONG ? 8 : mode == VX_MODE_NO_DDA ? 6 : 1;
+}
+
 // One thread per pixel, one wave per 8x8 pixel tile, 4 waves (16x16 pixels) per block.
 template <int MODE, int LAYOUT>
-__global__ __launch_bounds__(256) void render_generic(const VxParams p, const DevVolume v,
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(generic_min_waves(MODE), 8))) void render_generic(const VxParams p, const DevVolume v,
                                                        const float4* __restrict__ tf_global,
                                                        uint32_t tf_len, float4* __restrict__ slab,
                                                        uint32_t frame, float weight, const TileMap tm,
