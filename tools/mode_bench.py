@@ -19,7 +19,9 @@ def scene(vox, sp, w, h, shard=(0, 1)):
     return r
 
 
-def measure(r, label, frames=16, in_flight=8, **extra):
+def measure(r, label, frames=64, in_flight=32, **extra):
+    frames = int(os.environ.get("MB_FRAMES", frames))
+    in_flight = int(os.environ.get("MB_INFLIGHT", in_flight))
     r.bind_uniforms()
     r.render(frames=4, rebind=False); r.finish(); r.reset_counters()
     r.render(frames=frames, rebind=False, in_flight=in_flight); r.finish()
@@ -35,7 +37,7 @@ del vox
 for mode, bounces in (("dvr", 1), ("dvr_phong", 1), ("raymarch", 1), ("no_dda", 1), ("default", 1), ("default", 3)):
     r.settings.render_mode = mode
     r.settings.bounces = bounces
-    measure(r, f"config3 512^3 1080p {mode} bounces={bounces}", frames=8 if mode != "dvr" else 16)
+    measure(r, f"config3 512^3 1080p {mode} bounces={bounces}")
 r.close()
 vox, sp = synth.ct_phantom(256)
 r = scene(vox, sp, 1920, 1080)

@@ -357,17 +357,28 @@ static int ensure_counters(VxContext* c, size_t waves) {
 }
 
 template <int MODE>
-static void launch_generic(VxContext* c, uint32_t frame, float weight, dim3 grid, size_t lds, float4* out,
-                           DevCounters* dc, hipStream_t stream) {
+static void launch_generic(VxContext* c, const MultiOut& mo, float weight, dim3 grid, size_t lds, hipStream_t stream) {
+  grid.x *= mo.count ? mo.count : 1u;
   if (c->layout == VX_LAYOUT_BRICKF32)
     hipLaunchKernelGGL((render_generic<MODE, LAYOUT_BF>), grid, dim3(256), lds, stream, c->params,
-                       c->dv, c->tf, c->tf_len, out, frame, weight, c->tm, dc);
+                       c->dv, c->tf, c->tf_len, mo, weight, c->tm);
   else if (c->layout == VX_LAYOUT_CELLQUAD)
     hipLaunchKernelGGL((render_generic<MODE, LAYOUT_CQ>), grid, dim3(256), lds, stream, c->params,
-                       c->dv, c->tf, c->tf_len, out, frame, weight, c->tm, dc);
+                       c->dv, c->tf, c->tf_len, mo, weight, c->tm);
   else
     hipLaunchKernelGGL((render_generic<MODE, LAYOUT_REF>), grid, dim3(256), lds, stream, c->params,
-                       c->dv, c->tf, c->tf_len, out, frame, weight, c->tm, dc);
+                       c->dv, c->tf, c->tf_len, mo, weight, c->tm);
+}
+
+static void launch_generic_mode(VxContext* c, const MultiOut& mo, float weight, dim3 grid, hipStream_t stream) {
+  size_t lds = c->tf_len <= TF_LDS_MAX ? (size_t)c->tf_len * sizeof(float4) : 0;
+  switch (c->params.render_mode) {
+    case VX_MODE_DEFAULT: launch_generic<VX_MODE_DEFAULT>(c, mo, weight, grid, lds, stream); break;
+    case VX_MODE_NO_DDA: launch_generic<VX_MODE_NO_DDA>(c, mo, weight, grid, lds, stream); break;
+    case VX_MODE_RAYMARCH: launch_generic<VX_MODE_RAYMARCH>(c, mo, weight, grid, lds, stream); break;
+    case VX_MODE_DVR: launch_generic<VX_MODE_DVR>(c, mo, weight, grid, lds, stream); break;
+    default: launch_generic<VX_MODE_DVR_PHONG>(c, mo, weight, grid, lds, stream); break;
+  }
 }
 
 extern "C" {
@@ -743,13 +754,12 @@ static hipError_t launch_render(VxContext* c, uint32_t frame_index, float weight
     launch_dvr_cq(c->params, c->dv, c->tf, c->tf_len, out, frame_index, weight, c->tm, dc, stream,
                   (c->use_order && !c->dp_active()) ? c->order : nullptr);
   } else {
-    switch (mode) {
-      case VX_MODE_DEFAULT: launch_generic<VX_MODE_DEFAULT>(c, frame_index, weight, grid, lds, out, dc, stream); break;
-      case VX_MODE_NO_DDA: launch_generic<VX_MODE_NO_DDA>(c, frame_index, weight, grid, lds, out, dc, stream); break;
-      case VX_MODE_RAYMARCH: launch_generic<VX_MODE_RAYMARCH>(c, frame_index, weight, grid, lds, out, dc, stream); break;
-      case VX_MODE_DVR: launch_generic<VX_MODE_DVR>(c, frame_index, weight, grid, lds, out, dc, stream); break;
-      default: launch_generic<VX_MODE_DVR_PHONG>(c, frame_index, weight, grid, lds, out, dc, stream); break;
-    }
+    MultiOut mo{};
+    mo.count = 1;
+    mo.out[0] = out;
+    mo.dc[0] = dc;
+    mo.frame[0] = frame_index;
+    launch_generic_mode(c, mo, weight, grid, stream);
   }
   return hipGetLastError();
 }
@@ -856,9 +866,10 @@ int vx_render_frames(VxContext* c, uint32_t first_frame, uint32_t count, const f
   if ((rc = take_events(c, ev))) return rc;
   ev.launches = count - done;
   hipError_t le = hipSuccess;
-  if (is_tuned(c) && c->layout == VX_LAYOUT_CELLQUAD && !c->dp_active()) {
+  const bool tuned_cq = is_tuned(c) && c->layout == VX_LAYOUT_CELLQUAD && !c->dp_active();
+  if (tuned_cq || !is_tuned(c)) {
     // several frames per launch (see MultiOut): one kernel for up to in_flight frames, then the
-    // ordered blend of their results
+    // ordered blend of their results (the tuned cellquad DVR kernel and every render_generic mode)
     const uint32_t nqm = (uint32_t)c->slab_quads;
     c->free_events.push_back(ev);   // per-launch intervals instead of one batch interval
     while (done < count && le == hipSuccess) {
@@ -877,8 +888,11 @@ int vx_render_frames(VxContext* c, uint32_t first_frame, uint32_t count, const f
       EventPair e2;
       if ((rc = take_events(c, e2))) return rc;
       VX_HIP(c, hipEventRecord(e2.a, c->stream));
-      launch_dvr_cq_multi(c->params, c->dv, c->tf, c->tf_len, mo, 0.0f, c->tm, c->stream,
-                          c->use_order ? c->order : nullptr);
+      if (tuned_cq)
+        launch_dvr_cq_multi(c->params, c->dv, c->tf, c->tf_len, mo, 0.0f, c->tm, c->stream,
+                            c->use_order ? c->order : nullptr);
+      else
+        launch_generic_mode(c, mo, 0.0f, grid, c->stream);
       le = hipGetLastError();
       VX_HIP(c, hipEventRecord(e2.b, c->stream));   // the render kernel alone; the blend is outside
       c->pending_events.push_back(e2);
@@ -893,7 +907,8 @@ int vx_render_frames(VxContext* c, uint32_t first_frame, uint32_t count, const f
     if (le != hipSuccess) VX_FAIL(c, VX_ERR_DEVICE, "render kernel launch: %s", hipGetErrorString(le));
     return VX_OK;
   }
-  // other kernels: rolling window of frames on separate streams
+  // the LDS-tile DVR kernel (brickf32) and the depth-parallel experiment: rolling window of frames on
+  // separate streams
   VX_HIP(c, hipEventRecord(ev.a, c->stream));
   // rolling window: frame f renders on slot f % in_flight as soon as that slot's previous result has
   // been blended; the blends happen on the main stream, in frame order

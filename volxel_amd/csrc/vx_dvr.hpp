@@ -64,16 +64,6 @@ VXD void dvr_store(const VxParams& p, const DevVolume& dv, const DvrRay& r, floa
   slab[si] = o;
 }
 
-// Several independent accumulation frames in ONE launch: launch slot s renders frame slot s % count
-// of logical block order[s / count], so the longest blocks of all frames start first and the
-// latency-bound tail is paid once per `count` frames.  count == 1 is the plain per-frame launch.
-struct MultiOut {
-  float4* out[MERGE_MAX];
-  DevCounters* dc[MERGE_MAX];
-  uint32_t frame[MERGE_MAX];
-  uint32_t count;
-};
-
 // U = march steps per loop iteration: the 2*U gathers of a batch are issued back to back before
 // any of them is consumed, so a wave keeps 2*U loads in flight instead of 2 (the march is
 // latency-bound on the longest rays: tools/tail_probe.py).

@@ -78,13 +78,25 @@ VXD void add_counts(DevCounters* dc, uint32_t samples, uint32_t rays, uint32_t p
   }
 }
 
-VXD void flush_counts(DevCounters* dc, const Counts& c, uint32_t pixels) {
+VXD void flush_counts(DevCounters* dc, const Counts& c, uint32_t pixels, uint32_t block = 0xffffffffu) {
   uint32_t s = wave_sum(c.samples), r = wave_sum(c.rays), k = wave_sum(c.skips),
            g = wave_sum(c.grads), px = wave_sum(pixels);
-  add_counts(dc, s, r, px, k, g, 0u);
+  add_counts(dc, s, r, px, k, g, 0u, block);
 }
 
 constexpr uint32_t TF_LDS_MAX = 2048;  // entries staged in LDS (32 KiB); longer LUTs stay in L1/L2
+
+// Several independent accumulation frames in ONE launch: launch slot s renders frame slot s % count
+// of logical block s / count (through `order` in the tuned DVR kernel), so the latency-bound tail of a
+// frame is filled by the blocks of the other frames and paid once per launch.  count == 1 is the plain
+// per-frame launch.  merge_results then applies the running-mean blends in frame order.
+constexpr int MERGE_MAX = 32;  // frames per launch
+struct MultiOut {
+  float4* out[MERGE_MAX];
+  DevCounters* dc[MERGE_MAX];
+  uint32_t frame[MERGE_MAX];
+  uint32_t count;
+};
 
 // Occupancy the register allocator is asked for, per mode.  The path-traced modes are bound by latency and
 // divergence (about 37 % of the lane slots of an issued VALU instruction do work), so more resident waves
@@ -99,9 +111,8 @@ constexpr int generic_min_waves(int mode) {
 template <int MODE, int LAYOUT>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(generic_min_waves(MODE), 8))) void render_generic(const VxParams p, const DevVolume v,
                                                        const float4* __restrict__ tf_global,
-                                                       uint32_t tf_len, float4* __restrict__ slab,
-                                                       uint32_t frame, float weight, const TileMap tm,
-                                                       DevCounters* __restrict__ dc) {
+                                                       uint32_t tf_len, const MultiOut mo, float weight,
+                                                       const TileMap tm) {
   extern __shared__ float4 tf_lds[];
   TfView tf;
   tf.len = tf_len;
@@ -113,8 +124,13 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(generic_min
   } else {
     tf.lut = tf_global;
   }
+  const uint32_t fslot = mo.count > 1 ? blockIdx.x % mo.count : 0u;
+  const uint32_t blk = mo.count > 1 ? blockIdx.x / mo.count : blockIdx.x;
+  float4* __restrict__ slab = mo.out[fslot];
+  DevCounters* __restrict__ dc = mo.dc[fslot];
+  const uint32_t frame = mo.frame[fslot];
   uint32_t lt, sub;
-  if (!block_to_tile(blockIdx.x, tm, lt, sub)) return;
+  if (!block_to_tile(blk, tm, lt, sub)) return;
   uint32_t wt = sub * 4u + (threadIdx.x >> 6), lane = threadIdx.x & 63u;
   int px, py;
   uint32_t si;
@@ -133,7 +149,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(generic_min
     o.w = 1.0f;
     slab[si] = o;
   }
-  flush_counts(dc, c, active ? 1u : 0u);
+  flush_counts(dc, c, active ? 1u : 0u, blk);
 }
 
 // ---- longest-processing-time-first launch order, fed back from the previous frame ------------
@@ -211,7 +227,6 @@ __global__ __launch_bounds__(256) void build_brickf32(const DevVolume v, float* 
 }
 
 // ---- ordered running-mean blend of pipelined frame results (fragment.frag:158 applied n times) ----
-constexpr int MERGE_MAX = 32;  // frames per launch of the multi-frame DVR kernel (MultiOut)
 struct MergeArgs {
   const float4* result[MERGE_MAX];
   float weight[MERGE_MAX];
