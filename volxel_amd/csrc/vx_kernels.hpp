@@ -100,11 +100,19 @@ struct MultiOut {
 
 // Occupancy the register allocator is asked for, per mode.  The path-traced modes are bound by latency and
 // divergence (about 37 % of the lane slots of an issued VALU instruction do work), so more resident waves
-// pay even at the price of a few spills: measured on config 3 (tools/variant_modes.sh, ms per frame, free /
-// 6 / 8 waves per SIMD): default 0.825 / 0.755 / 0.697, default with 3 bounces 2.54 / 2.30 / 2.04, no_dda
-// 0.986 / 0.925 / 0.954, raymarch 1.22 / 1.24 / 1.25, dvr_phong 1.03 / 1.03 / 0.97.
+// pay even at the price of a few spills: measured on config 3 (tools/variant_modes.sh, ms per frame, 32 frames
+// per launch, 5 / 6 / 8 waves per SIMD): default 0.705 / 0.635 / 0.568, default with 3 bounces 2.31 / 2.06 /
+// 1.79, no_dda 0.804 / 0.744 / 0.726, raymarch 1.070 / 1.062 / 1.048, dvr_phong 0.831 / 0.828 / 0.762.
+// (-DVX_W_DEFAULT=.. -DVX_W_NO_DDA=.. -DVX_W_RAYMARCH=.. -DVX_W_PHONG=.. through EXTRA rebuilds a variant.)
+#ifndef VX_W_DEFAULT
+#define VX_W_DEFAULT 8
+#define VX_W_NO_DDA 8
+#define VX_W_RAYMARCH 8
+#define VX_W_PHONG 8
+#endif
 constexpr int generic_min_waves(int mode) {
-  return mode == VX_MODE_DEFAULT || mode == VX_MODE_DVR_PHONG ? 8 : mode == VX_MODE_NO_DDA ? 6 : 1;
+  return mode == VX_MODE_DEFAULT ? VX_W_DEFAULT : mode == VX_MODE_DVR_PHONG ? VX_W_PHONG
+         : mode == VX_MODE_NO_DDA ? VX_W_NO_DDA : mode == VX_MODE_RAYMARCH ? VX_W_RAYMARCH : 1;
 }
 
 // One thread per pixel, one wave per 8x8 pixel tile, 4 waves (16x16 pixels) per block.
