@@ -128,6 +128,7 @@ def main():
     ap.add_argument("--frames-per-launch", type=int, default=32,
                     help="independent accumulation frames rendered by one kernel launch (1..32)")
     ap.add_argument("--no-skip-variant", action="store_true", help="do not run the secondary measurement with skipping")
+    ap.add_argument("--no-mode-variants", action="store_true", help="do not time the other render modes afterwards")
     ap.add_argument("--force-gather", action="store_true", help="run the gather path with one rank too (testing)")
     a = ap.parse_args()
 
@@ -292,6 +293,20 @@ def main():
                 "ms_per_frame": round(cs.kernel_ms / cs.frames, 4),
                 "samples_per_frame": int(cs.samples // cs.frames),
                 "gsamples_per_s": round(cs.samples / cs.kernel_ms / 1e6, 1)}
+            r.settings.dvr_skip_empty = False
+        if world == 1 and not a.no_mode_variants:
+            # the other render modes on the same scene (kernel ms per accumulation frame; not the metric)
+            other = {}
+            for mode, bounces in (("dvr_phong", 1), ("default", 1), ("no_dda", 1), ("raymarch", 1)):
+                r.settings.render_mode, r.settings.bounces = mode, bounces
+                r.restart_rendering()
+                r.bind_uniforms()
+                r.render(frames=3, rebind=False); r.finish(); r.reset_counters()
+                r.render(frames=32, rebind=False, in_flight=P); r.finish()
+                cs = r.counters()
+                other[mode] = {"ms_per_frame": round(cs.kernel_ms / cs.frames, 4),
+                               "samples_per_frame": int(cs.samples // cs.frames)}
+            out["config"]["other_modes"] = other
         real_stdout.write(json.dumps(out) + "\n")
         real_stdout.flush()
     if use_dist:
