@@ -745,8 +745,6 @@ static bool is_tuned(const VxContext* c) {
 // one render-kernel launch into `out` (accumulator or a pipeline result slab)
 static hipError_t launch_render(VxContext* c, uint32_t frame_index, float weight, dim3 grid, float4* out,
                                 DevCounters* dc, hipStream_t stream) {
-  size_t lds = c->tf_len <= TF_LDS_MAX ? (size_t)c->tf_len * sizeof(float4) : 0;
-  int mode = c->params.render_mode;
   bool tuned = is_tuned(c);
   if (tuned && c->layout == VX_LAYOUT_BRICKF32) {
     launch_dvr_tile(c->params, c->dv, c->tf, c->tf_len, out, frame_index, weight, c->tm, dc, stream);
