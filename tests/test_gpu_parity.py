@@ -292,7 +292,7 @@ def test_empty_space_skipping_is_exact(oracle, layout):
     assert counts[0] < counts[1]
 
 
-@pytest.mark.parametrize("mode", ["dvr", "raymarch"])
+@pytest.mark.parametrize("mode", ["dvr", "dvr_phong", "raymarch", "default", "no_dda"])
 def test_pipelined_frames_are_bit_identical(oracle, mode):
     """vx_render_frames with several frames in flight == the same frames one by one"""
     from tests.common import make_scene, benchmark_tf, BENCH_CAM
