@@ -481,6 +481,11 @@ static int build_layout(VxContext* c) {
   if (c->layout != VX_LAYOUT_CELLQUAD) return VX_OK;
   for (int i = 0; i < 3; ++i) c->dv.cq_bc[i] = c->dv.bc[i] + 1;
   uint64_t n_quads = (uint64_t)c->dv.cq_bc[0] * c->dv.cq_bc[1] * c->dv.cq_bc[2] * CQ_BRICK_QUADS;
+  // the march indexes quads with 32 bits (and bricks with 24-bit multiplies): 64 GiB, about 1550^3 voxels
+  if (n_quads > 0xffffffffull)
+    VX_FAIL(c, VX_ERR_INVALID,
+            "volume too large for the cellquad layout (%llu quads > 2^32): select VX_LAYOUT_BRICKF32 or "
+            "VX_LAYOUT_REFERENCE with vx_set_layout", (unsigned long long)n_quads);
   VX_HIP(c, hipMalloc(&c->cq_alloc, n_quads * sizeof(float4)));
   c->dv.cq = (const float4*)c->cq_alloc;
   uint64_t blocks = (n_quads + 255) / 256;
