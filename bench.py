@@ -130,6 +130,8 @@ def main():
     ap.add_argument("--no-skip-variant", action="store_true", help="do not run the secondary measurement with skipping")
     ap.add_argument("--no-mode-variants", action="store_true", help="do not time the other render modes afterwards")
     ap.add_argument("--force-gather", action="store_true", help="run the gather path with one rank too (testing)")
+    ap.add_argument("--no-balance", action="store_true",
+                    help="N>1: keep the default round-robin dealing of the 64x64 tiles instead of the cost-balanced order")
     a = ap.parse_args()
 
     # the contract is ONE JSON line on stdout: keep a private handle to the real stdout and send
@@ -159,6 +161,11 @@ def main():
     if a.layout is not None:
         r.set_layout(a.layout)
     r.bind_uniforms()
+    if world > 1 and not a.no_balance:
+        # every rank probes the same 510 tile costs on its own GPU and derives the same dealing order:
+        # no communication, equal tile counts per rank, the gathered image stays bit-identical
+        r.balance_tiles()
+        r.bind_uniforms()
 
     gathered = image = slab = snap = None
     rs = cs = None
@@ -264,7 +271,8 @@ def main():
                 "workload": f"config3: {a.volume}^3 value-noise volume (seed 42), {a.width}x{a.height}, "
                             "DVR trilinear + 128-entry TF LUT (benchmark.json stops), step 0.5 voxel, "
                             "ERT eps 1e-4, clip box (0.25,0,0)-(1,1,0.75)",
-                "parallelism": (f"image-tiles x{world} (64x64 tiles round-robin, volume replicated, RCCL "
+                "parallelism": (f"image-tiles x{world} (64x64 tiles, "
+                                f"{'round-robin' if a.no_balance else 'cost-balanced dealing order'}, volume replicated, RCCL "
                                 f"all_gather of the framebuffer every {a.gather_every} frames, overlapped)")
                                if use_dist else "1 GPU",
                 "gathers": state["gathers"],

@@ -207,6 +207,18 @@ int vx_render_frame(VxContext* ctx, uint32_t frame_index, float sample_weight);
  * vx_render_frame.  [build] no reference counterpart: WebGL2 draws are serialised. */
 int vx_render_frames(VxContext* ctx, uint32_t first_frame, uint32_t count, const float* weights, int in_flight);
 
+/* ---- multi-GPU load balance (no counterpart in the reference).  By default tile t of the 64x64 tile grid
+ *      (row-major) belongs to shard t % shard_count.  vx_set_tile_order installs another dealing order:
+ *      position pos holds tile perm[pos] and belongs to shard pos % shard_count (local index pos /
+ *      shard_count), so every shard still owns the same number of tiles.  perm must be a permutation of
+ *      0..n_tiles-1 and identical on all ranks; NULL restores the default.  The accumulator is cleared:
+ *      restart the accumulation (frame 0) afterwards.  vx_probe_tile_costs fills costs[t] with a cost
+ *      estimate of every tile of the image (DVR samples of 64 probe rays per tile, current volume /
+ *      transfer function / params) -- the same numbers on every rank, so sorting them gives every rank the
+ *      same order without communication. */
+int vx_probe_tile_costs(VxContext* ctx, uint32_t* costs, uint32_t n_tiles);
+int vx_set_tile_order(VxContext* ctx, const uint32_t* perm, uint32_t n_tiles);
+
 /* current framebuffer size (what vx_read_accum / vx_read_display will write) */
 int vx_render_size(VxContext* ctx, uint32_t* width, uint32_t* height);
 

@@ -21,12 +21,13 @@ def _worker(rank, world, port, w, h, out_dir):
     os.environ["MASTER_PORT"] = str(port)
     dist.init_process_group("gloo", rank=rank, world_size=world)
     full = np.load(os.path.join(out_dir, "full.npy"))
-    px, py = tiles.slab_pixel_coords(w, h, rank, world)
-    slab = np.zeros((px.size, 4), dtype=np.float32)
-    ok = px >= 0
-    slab[ok] = full[py[ok], px[ok]]
-    img = gather_image(torch.from_numpy(slab.reshape(-1)), w, h)
-    np.save(os.path.join(out_dir, f"img{rank}.npy"), img.numpy())
+    for tag, perm in (("", None), ("_bal", np.load(os.path.join(out_dir, "perm.npy")))):
+        px, py = tiles.slab_pixel_coords(w, h, rank, world, perm)
+        slab = np.zeros((px.size, 4), dtype=np.float32)
+        ok = px >= 0
+        slab[ok] = full[py[ok], px[ok]]
+        img = gather_image(torch.from_numpy(slab.reshape(-1)), w, h, perm=perm)
+        np.save(os.path.join(out_dir, f"img{rank}{tag}.npy"), img.numpy())
     dist.barrier()
     dist.destroy_process_group()
 
@@ -42,10 +43,15 @@ def test_two_rank_gather_is_bit_identical(oracle, tmp_path, w, h):
     s, cam, vol, ds, p = make_scene(g, w, h, "dvr")
     full, _ = oracle.render(p, g, tf, L)
     np.save(tmp_path / "full.npy", full)
+    from volxel_amd import tiles
+    nt = tiles.tile_counts(w, h, 2)[2]
+    costs = np.random.default_rng(4).integers(0, 1000, size=nt)      # any costs: the order is a permutation
+    np.save(tmp_path / "perm.npy", tiles.balanced_order(costs, 2))
     port = 29500 + (os.getpid() % 2000)
     mp.spawn(_worker, args=(2, port, w, h, str(tmp_path)), nprocs=2, join=True)
     for rank in range(2):
         assert np.array_equal(np.load(tmp_path / f"img{rank}.npy"), full)
+        assert np.array_equal(np.load(tmp_path / f"img{rank}_bal.npy"), full)    # balanced dealing order
 
 
 def test_tile_partition_covers_every_pixel_once():
@@ -59,3 +65,18 @@ def test_tile_partition_covers_every_pixel_once():
             ok = px >= 0
             np.add.at(seen, (py[ok], px[ok]), 1)
         assert (seen == 1).all()
+        # a balanced dealing order is a permutation: the same holds, and the cost sums level out
+        costs = np.random.default_rng(n).gamma(2.0, 100.0, size=nt).astype(np.int64)
+        perm = tiles.balanced_order(costs, n)
+        assert sorted(perm.tolist()) == list(range(nt))
+        seen[:] = 0
+        for r in range(n):
+            px, py = tiles.slab_pixel_coords(w, h, r, n, perm)
+            ok = px >= 0
+            np.add.at(seen, (py[ok], px[ok]), 1)
+        assert (seen == 1).all()
+        if n > 1 and nt >= 8 * n:
+            dealt = [costs[perm[r::n]].sum() for r in range(n)]
+            plain = [costs[r::n].sum() for r in range(n)]
+            assert max(dealt) / np.mean(dealt) <= max(plain) / np.mean(plain) + 1e-9
+            assert max(dealt) / np.mean(dealt) < 1.02

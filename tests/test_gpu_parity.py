@@ -633,3 +633,58 @@ def test_fullsize_tile_shards_are_bit_identical(big_scene):
     torch.cuda.synchronize()
     keep.detile(gathered.data_ptr(), image.data_ptr()); keep.finish()
     assert np.array_equal(image.view(1080, 1920, 4).cpu().numpy(), base)
+
+
+def test_balanced_tile_order_is_bit_identical_and_levels_the_shards(big_scene):
+    """vx_probe_tile_costs / vx_set_tile_order: every shard derives the same dealing order from the probe,
+    the gathered image stays bit-identical to the unsharded one, the shard with the most samples is closer
+    to the mean than with the default round-robin dealing, the tuned kernel + 32 frames per launch included"""
+    import torch
+    from volxel_amd import Volxel3DRenderer, tiles
+    from volxel_amd.dist import slab_tensor
+    r, msg = big_scene
+    r.restart_rendering(); r.render(frames=3, in_flight=1); base = r.read_accum()
+    N = 8
+    perms, slabs, per_rank, plain = [], [], [], []
+    for rank in (0, 3, 7):                      # three of the eight shards are enough for the image check
+        rr = Volxel3DRenderer(1920, 1080, shard_rank=rank, shard_count=N)
+        rr.setup_from_grid(msg)
+        rr.settings = r.settings; rr.camera = r.camera; rr.env_strength = r.env_strength
+        rr.change_transfer_func(*r._tf)
+        rr.reset_counters(); rr.render(); rr.finish()
+        c = rr.counters()
+        plain.append(c.samples + c.skip_steps)
+        perms.append(rr.balance_tiles())
+        rr.reset_counters(); rr.render(frames=3, in_flight=1); rr.finish()
+        c = rr.counters()
+        per_rank.append((c.samples + c.skip_steps) // 3)
+        slabs.append((rank, slab_tensor(rr).clone()))
+        keep = rr
+    assert all(np.array_equal(perms[0], q) for q in perms[1:])
+    costs = keep.probe_tile_costs()
+    assert costs.shape == (510,) and costs.max() > 0 and np.array_equal(perms[0], tiles.balanced_order(costs, N))
+    gathered = torch.zeros(N * slabs[0][1].numel(), dtype=torch.float32, device="cuda")
+    for rank, sl in slabs:
+        gathered[rank * sl.numel():(rank + 1) * sl.numel()] = sl
+    image = torch.empty(1080 * 1920 * 4, dtype=torch.float32, device="cuda")
+    torch.cuda.synchronize()
+    keep.detile(gathered.data_ptr(), image.data_ptr()); keep.finish()
+    img = image.view(1080, 1920, 4).cpu().numpy()
+    px, py = [], []
+    for rank, _ in slabs:                       # pixels owned by the three rendered shards
+        x, y = tiles.slab_pixel_coords(1920, 1080, rank, N, perms[0])
+        ok = x >= 0
+        px.append(x[ok]); py.append(y[ok])
+    px, py = np.concatenate(px), np.concatenate(py)
+    assert np.array_equal(img[py, px], base[py, px])
+    r.reset_counters(); r.restart_rendering(); r.render()
+    c = r.counters()
+    mean = (c.samples + c.skip_steps) / N       # the probe's cost: marched steps, evaluated or skipped
+    dev = lambda xs: max(abs(x - mean) for x in xs) / mean
+    assert dev(per_rank) < 0.03 and dev(per_rank) < dev(plain), (dev(per_rank), dev(plain))
+    keep.set_tile_order(None)                   # back to the default dealing
+    keep.reset_counters(); keep.render(); keep.finish()
+    c = keep.counters()
+    assert c.samples + c.skip_steps == plain[-1]
+    with pytest.raises(Exception, match="permutation"):
+        keep.set_tile_order(np.zeros(510, dtype=np.uint32))

@@ -18,6 +18,11 @@ for n in shards:
             r.shard_rank, r.shard_count = rank, n
             r.restart_rendering()
             r.bind_uniforms()
+            if os.environ.get("SP_BALANCE", "1") != "0" and n > 1:
+                r.balance_tiles()
+            else:
+                r.set_tile_order(None)
+            r.bind_uniforms()
             r.render(frames=4, rebind=False); r.finish(); r.reset_counters()
             r.render(frames=2 * fpl, rebind=False, in_flight=fpl); r.finish()   # warm the pipes
             r.reset_counters()

@@ -109,6 +109,8 @@ def load_library():
         "vx_read_display": ([vp, vp, C.c_float, C.c_float], i32),
         "vx_read_display_scaled": ([vp, vp, u32, u32, C.c_float, C.c_float], i32),
         "vx_slab_info": ([vp, P(u64), P(u32)], i32),
+        "vx_probe_tile_costs": ([vp, vp, u32], i32),
+        "vx_set_tile_order": ([vp, vp, u32], i32),
         "vx_render_size": ([vp, P(u32), P(u32)], i32),
         "vx_slab_device_ptr": ([vp, P(vp)], i32),
         "vx_detile": ([vp, vp, vp], i32),

@@ -68,6 +68,8 @@ struct VxContext {
   uint32_t env_w = 0, env_h = 0;
   uchar4* display = nullptr;
   uint32_t display_cap = 0;  // pixels
+  uint32_t* tile_perm = nullptr;  // vx_set_tile_order: position -> tile, tile -> position (2 * n_tiles)
+  uint32_t tile_perm_n = 0;
   size_t slab_cap = 0, image_cap = 0;
 
   // counters / timing
@@ -153,6 +155,13 @@ static void update_tilemap(VxContext* c) {
   t.shard_count = c->has_params && c->params.shard_count > 0 ? (uint32_t)c->params.shard_count : 1u;
   t.shard_rank = c->has_params ? (uint32_t)c->params.shard_rank : 0u;
   t.tiles_per_shard = (t.n_tiles + t.shard_count - 1) / t.shard_count;
+  if (c->tile_perm && c->tile_perm_n != t.n_tiles) {  // the order belongs to another tile grid
+    (void)hipFree(c->tile_perm);
+    c->tile_perm = nullptr;
+    c->tile_perm_n = 0;
+  }
+  t.perm = c->tile_perm;
+  t.inv = c->tile_perm ? c->tile_perm + t.n_tiles : nullptr;
 }
 
 static int alloc_framebuffers(VxContext* c) {
@@ -435,6 +444,7 @@ void vx_destroy(VxContext* c) {
   if (c->slab) (void)hipFree(c->slab);
   if (c->image) (void)hipFree(c->image);
   if (c->display) (void)hipFree(c->display);
+  if (c->tile_perm) (void)hipFree(c->tile_perm);
   if (c->dc) (void)hipFree(c->dc);
   if (c->order) (void)hipFree(c->order);
   for (auto& p : c->pipes) {
@@ -1014,6 +1024,64 @@ int vx_read_display_scaled(VxContext* c, uint8_t* out, uint32_t ow, uint32_t oh,
 int vx_read_display(VxContext* c, uint8_t* out, float exposure, float gamma) {
   if (!c) return VX_ERR_INVALID;
   return vx_read_display_scaled(c, out, c->W, c->H, exposure, gamma);
+}
+
+int vx_probe_tile_costs(VxContext* c, uint32_t* costs, uint32_t n) {
+  if (!c || !costs) return VX_ERR_INVALID;
+  VX_DEV(c);
+  if (!c->has_volume) VX_FAIL(c, VX_ERR_NO_VOLUME, "vx_probe_tile_costs: no volume uploaded");
+  if (!c->has_params || !c->tf || !c->W) VX_FAIL(c, VX_ERR_INVALID, "vx_probe_tile_costs: params, transfer function and size first");
+  if (n != c->tm.n_tiles) VX_FAIL(c, VX_ERR_INVALID, "vx_probe_tile_costs: the image has %u tiles, not %u", c->tm.n_tiles, n);
+  dim3 grid;
+  int rc = prepare_render(c, grid);   // skip mask, environment pointers
+  if (rc) return rc;
+  uint32_t* d = nullptr;
+  VX_HIP(c, hipMalloc(&d, (size_t)n * 4));
+  if (c->layout == VX_LAYOUT_BRICKF32)
+    hipLaunchKernelGGL((probe_tile_costs<LAYOUT_BF>), dim3(n), dim3(64), 0, c->stream, c->params, c->dv, c->tf, c->tf_len, c->tm, d);
+  else if (c->layout == VX_LAYOUT_CELLQUAD)
+    hipLaunchKernelGGL((probe_tile_costs<LAYOUT_CQ>), dim3(n), dim3(64), 0, c->stream, c->params, c->dv, c->tf, c->tf_len, c->tm, d);
+  else
+    hipLaunchKernelGGL((probe_tile_costs<LAYOUT_REF>), dim3(n), dim3(64), 0, c->stream, c->params, c->dv, c->tf, c->tf_len, c->tm, d);
+  hipError_t le = hipGetLastError();
+  if (le == hipSuccess) le = hipMemcpyAsync(costs, d, (size_t)n * 4, hipMemcpyDeviceToHost, c->stream);
+  if (le == hipSuccess) le = hipStreamSynchronize(c->stream);
+  (void)hipFree(d);
+  if (le != hipSuccess) VX_FAIL(c, VX_ERR_DEVICE, "vx_probe_tile_costs: %s", hipGetErrorString(le));
+  return VX_OK;
+}
+
+int vx_set_tile_order(VxContext* c, const uint32_t* perm, uint32_t n) {
+  if (!c) return VX_ERR_INVALID;
+  VX_DEV(c);
+  if (!c->W) VX_FAIL(c, VX_ERR_INVALID, "vx_set_tile_order: vx_resize first");
+  VX_HIP(c, hipStreamSynchronize(c->stream));
+  for (auto& p : c->pipes)
+    if (p.stream) VX_HIP(c, hipStreamSynchronize(p.stream));
+  if (perm) {
+    if (n != c->tm.n_tiles) VX_FAIL(c, VX_ERR_INVALID, "vx_set_tile_order: the image has %u tiles, not %u", c->tm.n_tiles, n);
+    std::vector<uint32_t> both(2 * (size_t)n, 0xffffffffu);
+    for (uint32_t pos = 0; pos < n; ++pos) {
+      uint32_t t = perm[pos];
+      if (t >= n || both[n + t] != 0xffffffffu) VX_FAIL(c, VX_ERR_INVALID, "vx_set_tile_order: not a permutation of the tiles");
+      both[pos] = t;
+      both[n + t] = pos;
+    }
+    if (c->tile_perm) (void)hipFree(c->tile_perm);
+    c->tile_perm = nullptr;
+    c->tile_perm_n = 0;
+    VX_HIP(c, hipMalloc(&c->tile_perm, both.size() * 4));
+    VX_HIP(c, hipMemcpy(c->tile_perm, both.data(), both.size() * 4, hipMemcpyHostToDevice));
+    c->tile_perm_n = n;
+  } else {
+    if (c->tile_perm) (void)hipFree(c->tile_perm);
+    c->tile_perm = nullptr;
+    c->tile_perm_n = 0;
+  }
+  update_tilemap(c);
+  if (c->slab) VX_HIP(c, hipMemsetAsync(c->slab, 0, c->slab_quads * sizeof(float4), c->stream));  // other tiles now
+  c->order_builds_left = 2;
+  return VX_OK;
 }
 
 int vx_render_size(VxContext* c, uint32_t* w, uint32_t* h) {

@@ -290,7 +290,7 @@ __global__ __launch_bounds__(256) void render_dvr_dp(const VxParams p, const Dev
   uint32_t si = 0;
   bool in_image;
   {
-    uint32_t t = lt * tm.shard_count + tm.shard_rank;
+    uint32_t t = tile_at(tm, lt);
     si = (lt * 64u + wt) * 64u + row * 8u + ray;
     in_image = t < tm.n_tiles;
     if (in_image) {

@@ -12,7 +12,15 @@ struct TileMap {
   uint32_t W, H;
   uint32_t tiles_x, tiles_y, n_tiles;
   uint32_t shard_rank, shard_count, tiles_per_shard;
+  // optional dealing order of the tiles (vx_set_tile_order): position pos = lt * shard_count + rank holds
+  // tile perm[pos]; inv is the inverse.  nullptr: pos == tile id (tiles dealt round-robin in row-major order).
+  const uint32_t* perm;
+  const uint32_t* inv;
 };
+VXD uint32_t tile_at(const TileMap& tm, uint32_t lt) {  // tile id of local tile lt, >= n_tiles: padding
+  uint32_t pos = lt * tm.shard_count + tm.shard_rank;
+  return (tm.perm && pos < tm.n_tiles) ? tm.perm[pos] : pos;
+}
 
 VXD uint32_t morton_x(uint32_t m) {  // compact even bits of a 6-bit code
   return (m & 1u) | ((m >> 1) & 2u) | ((m >> 2) & 4u);
@@ -30,7 +38,7 @@ VXD bool block_to_tile(uint32_t b, const TileMap& tm, uint32_t& lt, uint32_t& su
 
 VXD bool wave_pixel(const TileMap& tm, uint32_t lt, uint32_t wt, uint32_t lane, int& px, int& py,
                     uint32_t& slab_index) {
-  uint32_t t = lt * tm.shard_count + tm.shard_rank;
+  uint32_t t = tile_at(tm, lt);
   // hardware lane -> pixel of the 8x8 wave tile in Morton order: the address coalescer merges the
   // gathers of 4 consecutive lanes, and a 2x2 pixel block touches fewer cache lines than a 4x1 row.
   // The slab keeps its row-major slot order (slot = y*8 + x), so only the lane that owns a pixel moves.
@@ -160,6 +168,29 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(generic_min
   flush_counts(dc, c, active ? 1u : 0u, blk);
 }
 
+// Cost probe for the tile dealing order (vx_probe_tile_costs): one wave per 64x64 tile of the WHOLE image
+// whatever the shard, its lanes on the 8x8 grid of pixels 8 apart; cost = DVR samples (+ skipped steps / 8) of
+// those 64 primary rays at frame 0.  Every rank computes the same numbers, so every rank derives the same order.
+template <int LAYOUT>
+__global__ __launch_bounds__(64) void probe_tile_costs(const VxParams p, const DevVolume v,
+                                                        const float4* __restrict__ tf_global, uint32_t tf_len,
+                                                        const TileMap tm, uint32_t* __restrict__ costs) {
+  TfView tf;
+  tf.lut = tf_global;
+  tf.len = tf_len;
+  tf.lenf = (float)tf_len;
+  const uint32_t t = blockIdx.x, lane = threadIdx.x & 63u;
+  const int px = (int)((t % tm.tiles_x) * 64u + (lane & 7u) * 8u + 4u), py = (int)((t / tm.tiles_x) * 64u + (lane >> 3) * 8u + 4u);
+  Counts c{0, 0, 0, 0};
+  if ((uint32_t)px < tm.W && (uint32_t)py < tm.H) {
+    Frame<LAYOUT> f{p, v, tf, c};
+    (void)f.template shade_pixel<VX_MODE_DVR>(px, py, 0u);
+  }
+  // a step in an empty macro cell is tested or jumped over, not evaluated: about an eighth of a sample
+  uint32_t s = wave_sum(c.samples) + (wave_sum(c.skips) >> 3);
+  if (lane == 0) costs[t] = s;
+}
+
 // ---- longest-processing-time-first launch order, fed back from the previous frame ------------
 // The march is latency-bound on the longest rays: one wave that walks the whole volume needs
 // ~0.35 ms even on an idle GPU, so it must start first.  Progressive rendering repeats the same
@@ -264,7 +295,8 @@ __global__ __launch_bounds__(256) void detile(const float4* __restrict__ gathere
   uint32_t y = blockIdx.y * 16u + (threadIdx.x >> 4);
   if (x >= tm.W || y >= tm.H) return;
   uint32_t t = (y >> 6) * tm.tiles_x + (x >> 6);
-  uint32_t shard = t % tm.shard_count, lt = t / tm.shard_count;
+  uint32_t pos = tm.inv ? tm.inv[t] : t;
+  uint32_t shard = pos % tm.shard_count, lt = pos / tm.shard_count;
   uint32_t wx = (x >> 3) & 7u, wy = (y >> 3) & 7u;
   uint32_t wt = (wx & 1u) | ((wy & 1u) << 1) | ((wx & 2u) << 1) | ((wy & 2u) << 2) |
                 ((wx & 4u) << 2) | ((wy & 4u) << 3);

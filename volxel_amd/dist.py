@@ -27,10 +27,11 @@ def slab_tensor(renderer):
     return torch.as_tensor(_DevPtr(renderer.slab_device_ptr(), n), device=f"cuda:{torch.cuda.current_device()}")
 
 
-def gather_image(slab, width: int, height: int, renderer=None, group=None):
+def gather_image(slab, width: int, height: int, renderer=None, group=None, perm=None):
     """all_gather the per-rank slabs and de-tile.  `slab` is a 1-D float tensor (CUDA for the
     product path; CPU tensors are accepted so the partition/gather logic can be exercised with
-    the gloo backend).  Returns an [H, W, 4] tensor on the slab's device."""
+    the gloo backend; `perm` = the tile dealing order then, see tiles.balanced_order).  Returns an
+    [H, W, 4] tensor on the slab's device."""
     import torch
     import torch.distributed as dist
     world = dist.get_world_size(group) if dist.is_initialized() else 1
@@ -47,5 +48,5 @@ def gather_image(slab, width: int, height: int, renderer=None, group=None):
         renderer.detile(gathered.data_ptr(), image.data_ptr())
         renderer.finish()
         return image.view(height, width, 4)
-    img = tiles.detile_numpy(gathered.numpy().reshape(world, -1, 4), width, height, world)
+    img = tiles.detile_numpy(gathered.numpy().reshape(world, -1, 4), width, height, world, perm)
     return torch.from_numpy(img)

@@ -135,6 +135,7 @@ class Volxel3DRenderer:
         self.shard_rank, self.shard_count = shard_rank, shard_count
         self.low_resolution_duration = LOW_RESOLUTION_DURATION
         self.low_res_preview = bool(low_res_preview)
+        self.tile_order = None                                 # vx_set_tile_order permutation, if any
         self.resolution_factor = 1.0                           # viewer.ts:131, the ramp state
         if layout is not None:
             self._check(self._lib.vx_set_layout(self._ctx, int(layout)))
@@ -448,6 +449,35 @@ class Volxel3DRenderer:
         cus, mem = C.c_uint32(), C.c_uint64()
         self._check(self._lib.vx_device_info(self._ctx, name, 256, C.byref(cus), C.byref(mem)))
         return name.value.decode(), cus.value, mem.value
+
+    # -- multi-GPU load balance: dealing order of the 64x64 tiles (no counterpart in the reference) ----
+    def probe_tile_costs(self) -> np.ndarray:
+        """cost estimate of every tile of the image for the current volume / TF / uniforms (identical on
+        every rank)"""
+        from .tiles import tile_counts
+        self.bind_uniforms()
+        n = tile_counts(self.width, self.height, self.shard_count)[2]
+        costs = np.zeros(n, dtype=np.uint32)
+        self._check(self._lib.vx_probe_tile_costs(self._ctx, costs.ctypes.data, n))
+        return costs
+
+    def set_tile_order(self, perm):
+        """perm: position -> tile (a permutation, the same on all ranks) or None for the default dealing;
+        restarts the accumulation"""
+        if perm is None:
+            self._check(self._lib.vx_set_tile_order(self._ctx, None, 0))
+        else:
+            p = np.ascontiguousarray(perm, dtype=np.uint32)
+            self._check(self._lib.vx_set_tile_order(self._ctx, p.ctypes.data, p.size))
+        self.tile_order = None if perm is None else np.array(perm, dtype=np.uint32)
+        self.restart_rendering()
+
+    def balance_tiles(self):
+        """probe the tile costs and deal the tiles so that every shard gets an equal share of the work"""
+        from .tiles import balanced_order
+        perm = balanced_order(self.probe_tile_costs(), self.shard_count)
+        self.set_tile_order(perm)
+        return perm
 
     # -- zero-copy slab access for the RCCL gather (volxel_amd/dist.py) -----------------
     def slab_info(self):

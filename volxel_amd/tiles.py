@@ -25,9 +25,24 @@ def _morton6():
     return wx, wy
 
 
-def slab_pixel_coords(width: int, height: int, shard_rank: int, shard_count: int):
+def balanced_order(costs, shard_count: int) -> np.ndarray:
+    """Dealing order for vx_set_tile_order from per-tile cost estimates (vx_probe_tile_costs): tiles by
+    descending cost (ties by tile id), dealt to the shards in boustrophedon order -- 0..N-1, N-1..0, ... --
+    so that every shard gets one tile of every cost class and the running sums stay level.  Deterministic:
+    every rank derives the same permutation from the same costs."""
+    c = np.asarray(costs, dtype=np.int64)
+    order = np.argsort(-c, kind="stable")
+    n = int(shard_count)
+    out = order.copy()
+    for g in range(1, (len(order) + n - 1) // n, 2):
+        out[g * n:(g + 1) * n] = order[g * n:(g + 1) * n][::-1]
+    return out.astype(np.uint32)
+
+
+def slab_pixel_coords(width: int, height: int, shard_rank: int, shard_count: int, perm=None):
     """(px, py) int arrays of length tiles_per_shard*4096 giving the pixel of every slab slot,
-    -1 where the slot is padding (tile beyond the image or pixel beyond the border)."""
+    -1 where the slot is padding (tile beyond the image or pixel beyond the border).
+    perm: the dealing order installed with vx_set_tile_order (position -> tile), None = identity."""
     tx, ty, n, tps = tile_counts(width, height, shard_count)
     wx, wy = _morton6()
     lane = np.arange(64)
@@ -41,6 +56,8 @@ def slab_pixel_coords(width: int, height: int, shard_rank: int, shard_count: int
         t = lt * shard_count + shard_rank
         if t >= n:
             continue
+        if perm is not None:
+            t = int(perm[t])
         x = (t % tx) * TILE + ox
         y = (t // tx) * TILE + oy
         ok = (x < width) & (y < height)
@@ -49,12 +66,12 @@ def slab_pixel_coords(width: int, height: int, shard_rank: int, shard_count: int
     return px, py
 
 
-def detile_numpy(gathered: np.ndarray, width: int, height: int, shard_count: int) -> np.ndarray:
+def detile_numpy(gathered: np.ndarray, width: int, height: int, shard_count: int, perm=None) -> np.ndarray:
     """gathered: [shard_count, tiles_per_shard*4096, 4] -> image [height, width, 4]."""
     gathered = np.asarray(gathered).reshape(shard_count, -1, 4)
     img = np.zeros((height, width, 4), dtype=gathered.dtype)
     for r in range(shard_count):
-        px, py = slab_pixel_coords(width, height, r, shard_count)
+        px, py = slab_pixel_coords(width, height, r, shard_count, perm)
         ok = px >= 0
         img[py[ok], px[ok]] = gathered[r][ok]
     return img
