@@ -643,6 +643,7 @@ def test_balanced_tile_order_is_bit_identical_and_levels_the_shards(big_scene):
     from volxel_amd import Volxel3DRenderer, tiles
     from volxel_amd.dist import slab_tensor
     r, msg = big_scene
+    r.set_layout(1)                             # the shard contexts below use the default layout and kernel too
     r.restart_rendering(); r.render(frames=3, in_flight=1); base = r.read_accum()
     N = 8
     perms, slabs, per_rank, plain = [], [], [], []
