@@ -689,3 +689,43 @@ def test_balanced_tile_order_is_bit_identical_and_levels_the_shards(big_scene):
     assert c.samples + c.skip_steps == plain[-1]
     with pytest.raises(Exception, match="permutation"):
         keep.set_tile_order(np.zeros(510, dtype=np.uint32))
+
+
+def test_context_lifecycle_releases_device_memory(oracle):
+    """create / upload / every kind of render / resize / layout switch / destroy, twenty times: the free
+    device memory comes back (no leaked slabs, pipes, layouts, environment or order tables)"""
+    import gc
+    import torch
+    from tests.common import benchmark_tf
+    from volxel_amd import Environment, Volxel3DRenderer, synth
+    vox, sp = synth.value_noise(64, seed=3, zero_quantile=0.5)
+    g = oracle.BrickGrid(vox, sp)
+    tf, L = benchmark_tf()
+
+    def cycle(i):
+        r = Volxel3DRenderer(320 + 8 * i, 200, shard_rank=i % 2, shard_count=2, low_res_preview=bool(i & 1))
+        r.setup_from_grid(g)
+        r.change_transfer_func(tf, L)
+        r.set_environment(Environment(np.full((4, 8, 4), 0.5, dtype=np.float32), 8, 4))
+        for mode in ("dvr", "default", "dvr_phong"):
+            r.render_mode = mode
+            r.render(frames=12, in_flight=8)
+        r.balance_tiles()
+        r.set_layout(2)
+        r.settings.render_mode = "dvr"
+        r.render(frames=6, in_flight=4)
+        r.resize(256, 256)
+        r.set_layout(1)
+        r.render(frames=3)
+        img = r.read_display()
+        assert img.shape == (256, 256, 4)
+        r.close()
+
+    cycle(0)
+    gc.collect(); torch.cuda.synchronize()
+    free0 = torch.cuda.mem_get_info()[0]
+    for i in range(1, 21):
+        cycle(i)
+    gc.collect(); torch.cuda.synchronize()
+    free1 = torch.cuda.mem_get_info()[0]
+    assert free0 - free1 < 64 << 20, (free0 - free1) / 2 ** 20
