@@ -264,6 +264,7 @@ class Volxel3DRenderer:
         if (w, h) != (self.width, self.height):
             self.width, self.height = w, h
             self._check(self._lib.vx_resize(self._ctx, w, h))
+            self.tile_order = None   # a dealing order belongs to one tile grid; the library dropped it too
 
     def resize(self, width: int, height: int):
         if int(width) <= 0 or int(height) <= 0:
