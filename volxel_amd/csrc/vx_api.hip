@@ -715,6 +715,11 @@ int vx_resize(VxContext* c, uint32_t w, uint32_t h) {
   if (w == 0 || h == 0 || w > 16384 || h > 16384) VX_FAIL(c, VX_ERR_INVALID, "vx_resize: bad size %ux%u", w, h);
   VX_HIP(c, hipSetDevice(c->device));
   VX_HIP(c, hipStreamSynchronize(c->stream));
+  if ((w != c->W || h != c->H) && c->tile_perm) {  // a dealing order belongs to one image size
+    (void)hipFree(c->tile_perm);
+    c->tile_perm = nullptr;
+    c->tile_perm_n = 0;
+  }
   c->W = w;
   c->H = h;
   return alloc_framebuffers(c);
