@@ -84,6 +84,8 @@ def test_node_host_renders_like_the_oracle(oracle, tmp_path):
     json.dump(coll, open(tmp_path / "bench.json", "w"))
     _run(tmp_path, "gpu", str(tmp_path / "bench.json"))
     assert json.load(open(tmp_path / "pipelined.json")) == {"same": True, "frameIndex": 13}
+    tl = json.load(open(tmp_path / "tiles.json"))
+    assert tl["tiles"] == 2 and tl["nonzero"] >= 1 and "gfx950" in tl["device"]["name"] and tl["device"]["computeUnits"] == 256
     res = json.load(open(tmp_path / "benchmark_results.json"))
     assert [x["name"] for x in res] == ["default", "no_dda", "raymarch"]
     for x in res:                                                     # frames 0..6

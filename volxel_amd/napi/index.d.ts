@@ -35,6 +35,9 @@ export declare class Volxel3DDicomRenderer {
   startBenchmark(collection: { sharedSettings: any[]; benchmarks: any[] }, volumes?: Record<string, BrickGridMessage>): any[];
   bindUniforms(): { buffer: ArrayBuffer };
   render(frames?: number, inFlight?: number): void;
+  probeTileCosts(): Uint32Array;
+  setTileOrder(perm: Uint32Array | null): void;
+  deviceInfo(): { name: string; computeUnits: number; hbmBytes: number };
   finish(): void;
   readAccum(): Float32Array;
   readDisplay(): Uint8Array;

@@ -45,6 +45,15 @@ if (process.argv[3] === 'gpu') {
     for (let i = 0; same && i < a.length; ++i) same = a[i] === b[i];
     fs.writeFileSync(path.join(out, 'pipelined.json'), JSON.stringify({ same, frameIndex: r.frameIndex }));
   }
+  { // tile cost probe + a reversed dealing order: a single shard renders the same image in any order
+    const costs = r.probeTileCosts();
+    const perm = Uint32Array.from(costs.keys()).reverse();
+    r.render(3); const a = r.readAccum().slice();
+    r.setTileOrder(perm); r.render(r.frameIndex === 0 ? 16 : 0);
+    // frameIndex restarted at 0: render the same number of frames as before the switch
+    fs.writeFileSync(path.join(out, 'tiles.json'), JSON.stringify({ tiles: costs.length, nonzero: costs.filter(v => v > 0).length, device: r.deviceInfo() }));
+    r.setTileOrder(null);
+  }
   if (process.argv[4]) { // benchmark collection JSON -> result records (viewer.ts:856-890)
     const coll = JSON.parse(fs.readFileSync(process.argv[4], 'utf8'));
     fs.writeFileSync(path.join(out, 'benchmark_results.json'), JSON.stringify(r.startBenchmark(coll)));

@@ -344,7 +344,7 @@ class Volxel3DDicomRenderer {
           viewport: [0, 0, rf * this.canvasWidth, rf * this.canvasHeight],
           device: { platform: process.platform, userAgent: `node ${process.version} / volxel_hip ${native.version()}`,
             hardwareConcurrency: require('os').cpus().length, screen: { width: this.canvasWidth, height: this.canvasHeight, pixelRatio: 1 },
-            gpu: { vendor: 'AMD', renderer: 'gfx950', version: 'HIP' } },
+            gpu: { vendor: 'AMD', renderer: this.deviceInfo().name.trim(), version: 'HIP' } },
           timestamp: new Date(),
         })));
       }
@@ -354,6 +354,15 @@ class Volxel3DDicomRenderer {
     }
     return results;
   }
+  /** multi-GPU hosts: cost estimate of every 64x64 tile / dealing order of the tiles (volxel_hip.h) */
+  probeTileCosts() {
+    this.bindUniforms();
+    const n = Math.ceil(this.width / 64) * Math.ceil(this.height / 64), out = new Uint32Array(n);
+    native.probeTileCosts(this.ctx, out);
+    return out;
+  }
+  setTileOrder(perm) { native.setTileOrder(this.ctx, perm || null); this.restartRendering(); }
+  deviceInfo() { return native.deviceInfo(this.ctx); }
   finish() { native.finish(this.ctx); }
   readAccum() { const o = new Float32Array(this.width * this.height * 4); native.readAccum(this.ctx, o); return o; }
   readDisplay() { // the blit to the canvas (NEAREST, viewer.ts:310-311,1253-1265)

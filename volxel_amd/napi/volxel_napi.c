@@ -251,6 +251,55 @@ static napi_value n_render_frames(napi_env env, napi_callback_info info) {
   return NULL;
 }
 
+/* probeTileCosts(ctx, Uint32Array out): cost estimate of every 64x64 tile (vx_probe_tile_costs) */
+static napi_value n_probe_tile_costs(napi_env env, napi_callback_info info) {
+  napi_value a[2];
+  if (!get_args(env, info, 2, a)) return NULL;
+  VxContext* c = get_ctx(env, a[0]);
+  if (!c) return NULL;
+  void* d;
+  size_t n;
+  if (!typed(env, a[1], napi_uint32_array, &d, &n)) return NULL;
+  if (vx_probe_tile_costs(c, (uint32_t*)d, (uint32_t)n) != VX_OK) return throw_msg(env, vx_last_error(c));
+  return NULL;
+}
+
+/* setTileOrder(ctx, Uint32Array perm | null): dealing order of the tiles over the shards (vx_set_tile_order) */
+static napi_value n_set_tile_order(napi_env env, napi_callback_info info) {
+  napi_value a[2];
+  if (!get_args(env, info, 2, a)) return NULL;
+  VxContext* c = get_ctx(env, a[0]);
+  if (!c) return NULL;
+  napi_valuetype t;
+  NAPI_OK(napi_typeof(env, a[1], &t));
+  void* d = NULL;
+  size_t n = 0;
+  if (t != napi_null && t != napi_undefined && !typed(env, a[1], napi_uint32_array, &d, &n)) return NULL;
+  if (vx_set_tile_order(c, (const uint32_t*)d, (uint32_t)n) != VX_OK) return throw_msg(env, vx_last_error(c));
+  return NULL;
+}
+
+/* deviceInfo(ctx) -> { name, computeUnits, hbmBytes } */
+static napi_value n_device_info(napi_env env, napi_callback_info info) {
+  napi_value a[1];
+  if (!get_args(env, info, 1, a)) return NULL;
+  VxContext* c = get_ctx(env, a[0]);
+  if (!c) return NULL;
+  char name[256];
+  uint32_t cus = 0;
+  uint64_t hbm = 0;
+  if (vx_device_info(c, name, sizeof name, &cus, &hbm) != VX_OK) return throw_msg(env, vx_last_error(c));
+  napi_value o, v;
+  NAPI_OK(napi_create_object(env, &o));
+  NAPI_OK(napi_create_string_utf8(env, name, NAPI_AUTO_LENGTH, &v));
+  NAPI_OK(napi_set_named_property(env, o, "name", v));
+  NAPI_OK(napi_create_uint32(env, cus, &v));
+  NAPI_OK(napi_set_named_property(env, o, "computeUnits", v));
+  NAPI_OK(napi_create_double(env, (double)hbm, &v));
+  NAPI_OK(napi_set_named_property(env, o, "hbmBytes", v));
+  return o;
+}
+
 static napi_value n_finish(napi_env env, napi_callback_info info) {
   napi_value a[1];
   if (!get_args(env, info, 1, a)) return NULL;
@@ -493,7 +542,8 @@ static napi_value init(napi_env env, napi_value exports) {
   static const struct { const char* name; napi_callback fn; } fns[] = {
       {"create", n_create}, {"destroy", n_destroy}, {"uploadVolume", n_upload_volume},
       {"uploadTransfer", n_upload_transfer}, {"uploadEnvironment", n_upload_environment}, {"setParams", n_set_params}, {"sizeofParams", n_sizeof_params},
-      {"resize", n_resize}, {"setLayout", n_set_layout}, {"renderFrame", n_render_frame}, {"renderFrames", n_render_frames}, {"finish", n_finish},
+      {"resize", n_resize}, {"setLayout", n_set_layout}, {"renderFrame", n_render_frame}, {"renderFrames", n_render_frames},
+      {"probeTileCosts", n_probe_tile_costs}, {"setTileOrder", n_set_tile_order}, {"deviceInfo", n_device_info}, {"finish", n_finish},
       {"readAccum", n_read_accum}, {"readDisplay", n_read_display},
       {"readDisplayScaled", n_read_display_scaled}, {"getCounters", n_get_counters},
       {"resetCounters", n_reset_counters}, {"version", n_version}, {"buildBrickGrid", n_build_brick_grid},
