@@ -106,7 +106,7 @@ def traffic_from_profile(a):
     try:
         t = json.load(open(path))[key]
         if (t["width"], t["height"], t["volume"], t.get("frames_per_launch", 32)) != \
-                (a.width, a.height, a.volume, max(1, min(32, a.frames_per_launch))):
+                (a.width, a.height, a.volume, max(1, min(64, a.frames_per_launch))):
             return {"traffic": None}
         return {"traffic": int(t["hbm_bytes_per_launch"]), "traffic_source": t["source"]}
     except Exception:
@@ -116,17 +116,17 @@ def traffic_from_profile(a):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=64)
+    ap.add_argument("--steps", type=int, default=128)
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--width", type=int, default=1920)
     ap.add_argument("--height", type=int, default=1080)
     ap.add_argument("--volume", type=int, default=512)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--layout", type=int, default=None, help="0 reference, 1 cellquad (default), 2 brickf32 + LDS tiles")
-    ap.add_argument("--gather-every", type=int, default=32,
+    ap.add_argument("--gather-every", type=int, default=64,
                     help="N>1: all_gather the framebuffer once per this many accumulation frames")
-    ap.add_argument("--frames-per-launch", type=int, default=32,
-                    help="independent accumulation frames rendered by one kernel launch (1..32)")
+    ap.add_argument("--frames-per-launch", type=int, default=64,
+                    help="independent accumulation frames rendered by one kernel launch (1..64)")
     ap.add_argument("--no-skip-variant", action="store_true", help="do not run the secondary measurement with skipping")
     ap.add_argument("--no-mode-variants", action="store_true", help="do not time the other render modes afterwards")
     ap.add_argument("--force-gather", action="store_true", help="run the gather path with one rank too (testing)")
@@ -179,7 +179,7 @@ def main():
         gathered = torch.empty(world * slab.numel(), dtype=torch.float32, device="cuda")
         image = torch.empty(a.height * a.width * 4, dtype=torch.float32, device="cuda")
 
-    P = max(1, min(32, a.frames_per_launch))
+    P = max(1, min(64, a.frames_per_launch))
 
     def batch(f0, n):
         """n accumulation frames f0.. (n <= P): one launch, then -- at display cadence -- the gather"""
@@ -218,7 +218,7 @@ def main():
 
     def run(first, count, need_image=False):
         done, before = 0, state["gathers"]
-        while done < count:                   # equal launches: 40 frames at P = 32 go as 20 + 20
+        while done < count:                   # equal launches: 80 frames at P = 64 go as 40 + 40
             launches_left = -(-(count - done) // P)
             n = -(-(count - done) // launches_left)
             batch(first + done, n)
@@ -301,7 +301,7 @@ def main():
             r.settings.dvr_skip_empty = True
             r.bind_uniforms()
             r.render(frames=5, rebind=False); r.finish(); r.reset_counters()
-            r.render(frames=24, rebind=False, in_flight=P); r.finish()
+            r.render(frames=P, rebind=False, in_flight=P); r.finish()
             cs = r.counters()
             out["config"]["with_empty_space_skipping"] = {
                 "ms_per_frame": round(cs.kernel_ms / cs.frames, 4),
@@ -316,7 +316,7 @@ def main():
                 r.restart_rendering()
                 r.bind_uniforms()
                 r.render(frames=3, rebind=False); r.finish(); r.reset_counters()
-                r.render(frames=32, rebind=False, in_flight=P); r.finish()
+                r.render(frames=P, rebind=False, in_flight=P); r.finish()
                 cs = r.counters()
                 other[mode] = {"ms_per_frame": round(cs.kernel_ms / cs.frames, 4),
                                "samples_per_frame": int(cs.samples // cs.frames)}

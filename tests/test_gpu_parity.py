@@ -302,16 +302,16 @@ def test_pipelined_frames_are_bit_identical(oracle, mode):
     tf, L = benchmark_tf()
     s, cam, vol, ds, p = make_scene(g, 200, 120, mode, dvr_jitter=True, sample_range=(0.05, 1.0), **BENCH_CAM)
     out = []
-    for in_flight in (1, 4, 8, 32):
+    for in_flight in (1, 4, 8, 32, 64):
         r = _renderer(g, tf, L, p, 1)
         r.settings = s; r.camera = cam
         r.reset_counters()
         r.render(frames=3)                       # a few serial frames first
-        r.render(frames=37, in_flight=in_flight)  # 32 in flight: one full launch + a partial one
+        r.render(frames=69, in_flight=in_flight)  # 64 in flight: one full launch + a partial one
         out.append((r.read_accum(), r.counters().samples, r.frame_index))
-    assert out[0][2] == 40
+    assert out[0][2] == 72
     for img, n, fi in out[1:]:
-        assert np.array_equal(img, out[0][0]) and n == out[0][1] and fi == 40
+        assert np.array_equal(img, out[0][0]) and n == out[0][1] and fi == 72
 
 
 def test_display_pass_matches_blit(oracle):

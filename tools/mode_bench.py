@@ -19,7 +19,7 @@ def scene(vox, sp, w, h, shard=(0, 1)):
     return r
 
 
-def measure(r, label, frames=64, in_flight=32, **extra):
+def measure(r, label, frames=128, in_flight=64, **extra):
     frames = int(os.environ.get("MB_FRAMES", frames))
     in_flight = int(os.environ.get("MB_INFLIGHT", in_flight))
     r.bind_uniforms()

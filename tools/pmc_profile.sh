@@ -8,8 +8,8 @@ TAG=${1:-r01}; shift || true
 cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
 OUT=gpurun_out/prof/$TAG
 mkdir -p "$OUT"
-ARGS="--steps 64 --warmup 4 --no-cpu-baseline --no-skip-variant --no-mode-variants $*"
-timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/kt" -- python3 bench.py --steps 64 --warmup 5 --no-cpu-baseline --no-skip-variant --no-mode-variants "$@" > "$OUT/bench_kt.json" 2> "$OUT/bench_kt.err" || exit 1
+ARGS="--steps 128 --warmup 4 --no-cpu-baseline --no-skip-variant --no-mode-variants $*"
+timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/kt" -- python3 bench.py --steps 128 --warmup 5 --no-cpu-baseline --no-skip-variant --no-mode-variants "$@" > "$OUT/bench_kt.json" 2> "$OUT/bench_kt.err" || exit 1
 pass() {  # name counters...
   local name=$1; shift
   timeout -k 10 300 rocprofv3 --pmc "$@" --output-format csv -d "$OUT/$name" -- python3 bench.py $ARGS > "$OUT/bench_$name.json" 2> "$OUT/bench_$name.err" || { echo "pass $name failed"; tail -5 "$OUT/bench_$name.err"; return 1; }

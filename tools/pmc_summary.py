@@ -37,7 +37,7 @@ for d in sorted(glob.glob(os.path.join(root, "*"))):
     acc = defaultdict(list)
     for f in newest(os.path.join(d, "**", "*counter_collection.csv")):
         rows = [r for r in csv.DictReader(open(f)) if kern in r.get("Kernel_Name", "")]
-        # only the full-size launches (bench.py default: 32 frames per launch); the first frames of a run are
+        # only the full-size launches (bench.py default: 64 frames per launch); the first frames of a run are
         # launched one by one while the launch order is being built
         gmax = max((int(r["Grid_Size"]) for r in rows), default=0)
         for row in rows:
@@ -62,6 +62,6 @@ if len(sys.argv) > 3:
         out = {"cellquad": {"width": 1920, "height": 1080, "volume": 512, "fetch_size_kb": vals["fetch"],
                             "write_size_kb": vals["write"],
                             "hbm_bytes_per_launch": int((2 * vals["fetch"] + vals["write"]) * 1024),
-                            "source": sys.argv[3], "frames_per_launch": int(sys.argv[4]) if len(sys.argv) > 4 else 32}}
+                            "source": sys.argv[3], "frames_per_launch": int(sys.argv[4]) if len(sys.argv) > 4 else 64}}
         json.dump(out, open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "profiles", "traffic.json"), "w"), indent=1)
         print(f"\n## traffic.json: 2 x {vals['fetch']:.0f} KB + {vals['write']:.0f} KB per launch")

@@ -5,7 +5,7 @@ import sys, os, json
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from bench import build_scene
 
-fpls = [int(x) for x in (sys.argv[1] if len(sys.argv) > 1 else "8,16,32").split(",")]
+fpls = [int(x) for x in (sys.argv[1] if len(sys.argv) > 1 else "32,64").split(",")]
 shards = [int(x) for x in (sys.argv[2] if len(sys.argv) > 2 else "1,8").split(",")]
 base = {}
 r, msg, info = build_scene(1920, 1080, 512, 0, 1, 0)

@@ -98,7 +98,7 @@ constexpr uint32_t TF_LDS_MAX = 2048;  // entries staged in LDS (32 KiB); longer
 // of logical block s / count (through `order` in the tuned DVR kernel), so the latency-bound tail of a
 // frame is filled by the blocks of the other frames and paid once per launch.  count == 1 is the plain
 // per-frame launch.  merge_results then applies the running-mean blends in frame order.
-constexpr int MERGE_MAX = 32;  // frames per launch
+constexpr int MERGE_MAX = 64;  // frames per launch
 struct MultiOut {
   float4* out[MERGE_MAX];
   DevCounters* dc[MERGE_MAX];
