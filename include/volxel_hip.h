@@ -201,10 +201,11 @@ int vx_resize(VxContext* ctx, uint32_t width, uint32_t height);
 int vx_render_frame(VxContext* ctx, uint32_t frame_index, float sample_weight);
 
 /* The same for `count` consecutive accumulation frames (weights[i] = u_sample_weight of frame
- * first_frame + i), with up to `in_flight` (<= 8) of them rendered concurrently on separate HIP
- * streams.  Accumulation frames are independent given their index; only the running mean is ordered
- * and it is applied afterwards, in order -- the accumulator is bit-identical to `count` calls of
- * vx_render_frame.  [build] no reference counterpart: WebGL2 draws are serialised. */
+ * first_frame + i), with up to `in_flight` (<= 64) of them rendered by one kernel launch, each into its
+ * own result buffer.  Accumulation frames are independent given their index; only the running mean is
+ * ordered and it is applied afterwards, in order -- the accumulator is bit-identical to `count` calls of
+ * vx_render_frame.  Needs in_flight x (framebuffer + counters) of extra device memory.
+ * [build] no reference counterpart: WebGL2 draws are serialised. */
 int vx_render_frames(VxContext* ctx, uint32_t first_frame, uint32_t count, const float* weights, int in_flight);
 
 /* ---- multi-GPU load balance (no counterpart in the reference).  By default tile t of the 64x64 tile grid
