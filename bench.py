@@ -272,7 +272,7 @@ def main():
                             "DVR trilinear + 128-entry TF LUT (benchmark.json stops), step 0.5 voxel, "
                             "ERT eps 1e-4, clip box (0.25,0,0)-(1,1,0.75)",
                 "parallelism": (f"image-tiles x{world} (64x64 tiles, "
-                                f"{'round-robin' if a.no_balance else 'cost-balanced dealing order'}, volume replicated, RCCL "
+                                f"{'cost-balanced dealing order' if (world > 1 and not a.no_balance) else 'round-robin'}, volume replicated, RCCL "
                                 f"all_gather of the framebuffer every {a.gather_every} frames, overlapped)")
                                if use_dist else "1 GPU",
                 "gathers": state["gathers"],
