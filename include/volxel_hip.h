@@ -69,6 +69,11 @@ typedef struct VxParams {
      (utils.glsl:24,29,35); hoisted to the host (quirk Q11). */
   float camera_view_inv[16];
   float camera_proj_inv[16];
+  /* [build] 0: the reference's perspective ray (utils.glsl:23-40; scene.ts:65-72 is perspective
+     only).  1: orthographic -- parallel rays (BASELINE config 1): origin = the unprojected near-plane
+     point inverse(view)*inverse(proj)*(ndc.xy,-1,1), direction = normalize(inverse(view)*(0,0,-1,0));
+     camera_proj is then a gl-matrix ortho() matrix.                                              */
+  int32_t camera_ortho;
 
   /* fragment.frag:22, viewer.ts:1319-1320 (already clipped by volumeClipMin/Max) */
   float volume_aabb_min[3];
@@ -90,7 +95,8 @@ typedef struct VxParams {
   float light_dir[3];
   float env_strength;
   int32_t show_environment;
-  int32_t use_env; /* only 0 (directional light) is implemented; env maps are row N3     */
+  int32_t use_env; /* 0: directional light (environment.glsl:30-33); 1: the uploaded environment
+                      map (environment.glsl:35-79), needs vx_upload_environment first           */
   int32_t bounces;
 
   /* fragment.frag:44-51, viewer.ts:1351-1356 */
@@ -104,7 +110,7 @@ typedef struct VxParams {
   float dvr_ert_tau;     /* early ray termination once optical depth tau >= this
                             (= -ln(eps) for a transmittance threshold eps)               */
   int32_t dvr_jitter;    /* 1: sub-pixel + start jitter from the RNG like the reference
-                            (fragment.frag:146, raymarch.glsl:330); 0: pixel centre,
+                            (fragment.frag:146, raymarch.glsl:30); 0: pixel centre,
                             start offset 0.5 step                                        */
   int32_t dvr_max_steps;
   int32_t dvr_skip_empty; /* 1: exact empty-space skipping -- samples whose macro cell (16..64
@@ -133,6 +139,13 @@ typedef struct VxCounters {
   uint64_t frames;       /* accumulation frames rendered                                  */
   double kernel_ms;      /* sum of HIP-event durations of those launches                  */
   double last_kernel_ms; /* duration of the most recent launch                            */
+  uint64_t gathers;      /* 16-byte-per-lane gather instructions (global_load_dwordx4 wave
+                            instructions) issued by the tuned DVR kernels; 0 for the others  */
+  uint64_t lds_reads;    /* LDS tap reads (ds_read wave instructions) of the LDS-tile kernels  */
+  double merge_ms;       /* sum of HIP-event durations of the running-mean blend kernels that
+                            follow multi-frame launches (fragment.frag:158 applied in order)  */
+  uint32_t min_launch_frames; /* smallest / largest number of accumulation frames one launch  */
+  uint32_t max_launch_frames; /* actually covered (what ran, not what was requested)           */
 } VxCounters;
 
 typedef struct VxContext VxContext;
@@ -161,6 +174,13 @@ int vx_upload_volume(VxContext* ctx,
                      const uint8_t* atlas, const uint32_t atlas_size[3],
                      int n_mips, const uint16_t* const* mip_data, const uint32_t (*mip_size)[3],
                      const uint32_t index_extent[3]);
+
+/* facts of the last vx_upload_volume on this context: wall seconds (copies + device-side layout build,
+ * both inside the call), host bytes moved over PCIe, and whether the atlas could be pinned in place
+ * (hipHostRegister) so that the copy engine read it directly -- the "pin/upload volumes to HBM" step.
+ * The atlas goes in chunks of whole 8-slice layers and the layout of the brick layers a chunk completes is
+ * built behind it on a second stream.  Any out pointer may be NULL. */
+int vx_upload_stats(VxContext* ctx, double* seconds, uint64_t* host_bytes, int* pinned);
 
 /* the same straight from a native brick grid (volxel_brick.h): a C / Rust host that built the grid
  * with vxb_read_dicoms_to_grid or vxb_build_from_u16 uploads it without the copy-out of
@@ -256,6 +276,24 @@ int vx_reset_counters(VxContext* ctx);
 int vx_device_info(VxContext* ctx, char* name_out, uint32_t name_cap, uint32_t* cu_count,
                    uint64_t* hbm_bytes);
 const char* vx_version(void);
+
+/* test hook: the integer RNG of shaders/random.glsl evaluated ON THE DEVICE (rows A1/A2), one thread per
+ * output word.  op 0: out[i] = tea(a[i], b[i], 32) (random.glsl:41-51); op 1: out[i] = wangHash(a[i]) (:59-66);
+ * op 2: out[0..n) = the first n xoshiro128pp_next words of seedXoshiro(a[0]) (:69-94, quirk Q1);
+ * op 3: the same stream as rng() floats, bit patterns (:103-106).  a / b / out are host pointers.  */
+int vx_debug_rng(VxContext* ctx, int op, const uint32_t* a, const uint32_t* b, uint32_t n, uint32_t* out);
+
+/* measurement hook (no reference counterpart): what the vector L1 of this device sustains for the
+ * gather shape of the DVR march -- wave instructions of 16 bytes per lane whose 64 lane addresses
+ * fall into `lines` distinct L1-resident 128-byte lines (1..64), nothing else in the loop, 20 waves
+ * per CU, 8 gathers in flight per wave.  Returns the cost in clocks per gather instruction per CU at
+ * the device's nominal clock (clock_khz_out).  bench.py calls it for the roofline.l1 block. */
+int vx_probe_gather_rate(VxContext* ctx, uint32_t lines, double* clk_per_gather_out, uint32_t* clock_khz_out);
+/* measurement hook: re-march frame `frame_index` with the current volume / params and count, per gather
+ * instruction of the tuned cellquad DVR kernel, the distinct 128-byte lines its active lanes address
+ * (whole wave) and the line look-ups of its 16 groups of 4 consecutive lanes (what the L1 tag pipe sees).
+ * Nothing is written to the accumulator.  out3 = {gather instructions, distinct lines, quad look-ups}. */
+int vx_probe_gather_spread(VxContext* ctx, uint32_t frame_index, uint64_t out3[3]);
 
 /* test hook (no reference counterpart): the device's R8-unorm decode table, 256 floats */
 int vx_debug_unorm_table(VxContext* ctx, float* out256);

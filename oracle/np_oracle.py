@@ -212,6 +212,13 @@ def dvr_image(p, grid, tf, L, max_iter=100000):
     vv = [vp[i] / vp[3] for i in range(3)]
     wp = _mat_mul(p.camera_view_inv[:], vv[0], vv[1], vv[2], one)
     d = [wp[i] / wp[3] - cam[i] for i in range(3)]
+    if getattr(p, "camera_ortho", 0):
+        # [build] orthographic camera (BASELINE config 1): near-plane point of the pixel, camera -z axis
+        npt = _mat_mul(p.camera_proj_inv[:], fma(tex_x, F32(2), F32(-1)), fma(tex_y, F32(2), F32(-1)), -one, one)
+        wo = _mat_mul(p.camera_view_inv[:], npt[0] / npt[3], npt[1] / npt[3], npt[2] / npt[3], one)
+        cam = [wo[i] / wo[3] for i in range(3)]
+        wd = _mat_mul(p.camera_view_inv[:], zero, zero, -one, zero)
+        d = [wd[i] for i in range(3)]
     dd = fma(d[2], d[2], fma(d[1], d[1], d[0] * d[0]))
     inv = F32(1) / np.sqrt(dd)
     d = [a * inv for a in d]

@@ -112,7 +112,7 @@ def _has_fma():
 
 
 def build(force=False):
-    so = os.path.join(_HERE, "_ref", "libvx_oracle.so")
+    so = os.path.join(_HERE, "_build", "libvx_oracle.so")
     if force or not os.path.exists(so) or \
             os.path.getmtime(so) < os.path.getmtime(os.path.join(_HERE, "vx_oracle.c")):
         subprocess.check_call(["make", "-C", _HERE, "-s"])
@@ -127,7 +127,7 @@ def lib():
     if _lib is not None:
         return _lib
     name = "libvx_oracle.so" if _has_fma() else "libvx_oracle_nofma.so"
-    path = os.path.join(_HERE, "_ref", name)
+    path = os.path.join(_HERE, "_build", name)
     if not os.path.exists(path):
         build()
     L = C.CDLL(path)

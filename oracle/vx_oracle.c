@@ -1177,6 +1177,20 @@ static Ray setup_world_ray(const VxParams* p, float tex_x, float tex_y, float rx
   float x_off = fmaf(rx, 2.0f, -1.0f) * (1.0f / (float)p->res[0]);
   float y_off = fmaf(ry, 2.0f, -1.0f) * (1.0f / (float)p->res[1]);
   float sx = tex_x + x_off, sy = tex_y + y_off;
+  if (p->camera_ortho) {
+    /* [build] orthographic camera (BASELINE config 1; the reference camera is perspective only,
+       scene.ts:65-72): the ray starts at the unprojected near-plane point of the pixel and runs along
+       the camera's -z axis: o = inverse(view) * inverse(proj) * (ndc.xy, -1, 1), d = normalize(inverse(view)
+       * (0,0,-1,0)).  Same mat4 * vec4 fma chains and perspective divides as the perspective branch. */
+    float np_[4], wo[4], wd[4];
+    mat4_mul(p->camera_proj_inv, fmaf(sx, 2.0f, -1.0f), fmaf(sy, 2.0f, -1.0f), -1.0f, 1.0f, np_);
+    mat4_mul(p->camera_view_inv, np_[0] / np_[3], np_[1] / np_[3], np_[2] / np_[3], 1.0f, wo);
+    mat4_mul(p->camera_view_inv, 0.0f, 0.0f, -1.0f, 0.0f, wd);
+    Ray ro;
+    ro.o = V3(wo[0] / wo[3], wo[1] / wo[3], wo[2] / wo[3]);
+    ro.d = normalize3(V3(wd[0], wd[1], wd[2]));
+    return ro;
+  }
   /* cameraWorldPos */
   float cw[4];
   mat4_mul(p->camera_view_inv, 0.0f, 0.0f, 0.0f, 1.0f, cw);

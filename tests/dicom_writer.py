@@ -28,8 +28,9 @@ def _el(tag, vr: bytes, value: bytes, explicit: bool, undefined=False):
 
 def write_slice(pixels: np.ndarray, spacing=(0.5, 0.75), thickness=1.25, bits_stored=12,
                 syntax=EXPLICIT, bits_allocated=16, samples=1, signed=False, frames=None,
-                with_sequence=True, omit=()) -> bytes:
-    """pixels: [rows, cols] (or [frames, rows, cols]) uint16."""
+                with_sequence=True, omit=(), frames_text=None) -> bytes:
+    """pixels: [rows, cols] (or [frames, rows, cols]) uint16.  frames_text: write this NumberOfFrames
+    string instead of the true count (crafted-file tests)."""
     px = np.ascontiguousarray(pixels, dtype="<u2")
     if px.ndim == 2:
         px = px[None]
@@ -53,8 +54,8 @@ def write_slice(pixels: np.ndarray, spacing=(0.5, 0.75), thickness=1.25, bits_st
         ds += _el((0x18, 0x50), b"DS", _pad(repr(float(thickness)).encode()), explicit)
     ds += _el((0x28, 2), b"US", struct.pack("<H", samples), explicit)
     ds += _el((0x28, 4), b"CS", _pad(b"MONOCHROME2"), explicit)
-    if frames or nf > 1:
-        ds += _el((0x28, 8), b"IS", _pad(str(nf).encode()), explicit)
+    if frames or nf > 1 or frames_text is not None:
+        ds += _el((0x28, 8), b"IS", _pad((frames_text if frames_text is not None else str(nf)).encode()), explicit)
     ds += _el((0x28, 0x10), b"US", struct.pack("<H", rows), explicit)
     ds += _el((0x28, 0x11), b"US", struct.pack("<H", cols), explicit)
     if "spacing" not in omit:

@@ -103,3 +103,20 @@ def test_malformed_inputs(native_lib):
             vx.read_dicoms_to_grid([good[:cut]])
         except RuntimeError:
             pass
+
+
+@pytest.mark.parametrize("frames_text", ["2147483648", "4294967297", "65536", "99999999999999999999"])
+def test_crafted_frame_count_is_an_error_not_an_abort(native_lib, frames_text):
+    """NumberOfFrames far beyond the PixelData: rows*columns*frames*2 must not wrap the length check, and no
+    C++ exception (length_error / bad_alloc of the stack) may cross the C ABI -- ADVICE round 1."""
+    v = _stack(dims=(16, 8, 1))
+    with pytest.raises(RuntimeError, match="NumberOfFrames|PixelData"):
+        vx.read_dicoms_to_grid([write_slice(v[0], frames_text=frames_text)])
+
+
+def test_stack_deeper_than_the_brick_limit_is_an_error(native_lib):
+    """8128 slices is the deepest stack the 10-bit pointers allow (brick.rs:77-81)"""
+    v = np.zeros((1, 8, 8), dtype=np.uint16)
+    one = write_slice(np.repeat(v, 4100, axis=0))
+    with pytest.raises(RuntimeError, match="8128"):
+        vx.read_dicoms_to_grid([one, one])

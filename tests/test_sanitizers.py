@@ -18,6 +18,7 @@ def test_dicom_reader_and_brick_builder_under_asan_ubsan(tmp_path):
     for i, (syn, seq) in enumerate(((EXPLICIT, True), (IMPLICIT, True), (EXPLICIT, False))):
         (tmp_path / f"s{i}.dcm").write_bytes(write_slice(v[i], syntax=syn, with_sequence=seq))
     (tmp_path / "multi.dcm").write_bytes(write_slice(v, bits_stored=12, thickness=None))
+    (tmp_path / "crafted.dcm").write_bytes(write_slice(v[0], frames_text="2147483648"))
     src = open(os.path.join(ROOT, "tests", "sanitize_harness.cpp.in")).read().replace("%DIR%", str(tmp_path))
     (tmp_path / "harness.cpp").write_text(src)
     exe = str(tmp_path / "harness")
@@ -29,4 +30,5 @@ def test_dicom_reader_and_brick_builder_under_asan_ubsan(tmp_path):
     p = subprocess.run([exe], capture_output=True, text=True, timeout=600)
     assert p.returncode == 0, p.stderr[-2000:]
     assert "full: rc 0" in p.stdout and "multi: rc 0" in p.stdout and "rejected" in p.stdout
+    assert "crafted: rc 1" in p.stdout or "crafted: rc 2" in p.stdout, p.stdout
     assert "ERROR" not in p.stderr and "runtime error" not in p.stderr

@@ -119,6 +119,10 @@ def load_library():
         "vx_device_info": ([vp, C.c_char_p, u32, P(u32), P(u64)], i32),
         "vx_version": ([], C.c_char_p),
         "vx_debug_unorm_table": ([vp, vp], i32),
+        "vx_debug_rng": ([vp, i32, vp, vp, u32, vp], i32),
+        "vx_probe_gather_rate": ([vp, u32, P(C.c_double), P(u32)], i32),
+        "vx_probe_gather_spread": ([vp, u32, P(u64)], i32),
+        "vx_upload_stats": ([vp, P(C.c_double), P(u64), P(i32)], i32),
         "vx_debug_build_skip_mask": ([vp, P(u32), vp, u32, P(VxParams), vp, P(u32), P(u32)], i32),
         # preprocessor
         "vxb_build_from_u16": ([vp, P(u32), P(C.c_float), C.c_uint16, i32, P(vp)], i32),

@@ -18,6 +18,9 @@
 #include <cstdint>
 #include <cstring>
 #include <string>
+#include <memory>
+#include <new>
+#include <stdexcept>
 #include <thread>
 #include <vector>
 
@@ -116,9 +119,29 @@ const char* vxb_last_error(void) { return g_err.c_str(); }
 
 }  // extern "C"
 
-// shared by vxb_build_from_u16 and the DICOM reader; hist_bins == 0: 4096 / 65536 by max value
+static int build_internal_impl(const uint16_t* vox, const uint32_t dims[3], const float spacing[3], uint16_t max_value,
+                               uint32_t hist_bins, int n_threads, VxBrickGrid** out);
+
+// shared by vxb_build_from_u16 and the DICOM reader; hist_bins == 0: 4096 / 65536 by max value.
+// Exceptions (allocation failure, the brick-count limit) stop here: nothing crosses the C ABI.
 int vxb_build_internal(const uint16_t* vox, const uint32_t dims[3], const float spacing[3], uint16_t max_value,
                        uint32_t hist_bins, int n_threads, VxBrickGrid** out) {
+  if (out) *out = nullptr;
+  try {
+    return build_internal_impl(vox, dims, spacing, max_value, hist_bins, n_threads, out);
+  } catch (const std::bad_alloc&) {
+    g_err = "out of memory while building the brick grid";
+  } catch (const std::exception& e) {
+    g_err = e.what();
+  } catch (...) {
+    g_err = "unexpected failure while building the brick grid";
+  }
+  if (out) *out = nullptr;
+  return VXB_ERR_INVALID;
+}
+
+static int build_internal_impl(const uint16_t* vox, const uint32_t dims[3], const float spacing[3], uint16_t max_value,
+                               uint32_t hist_bins, int n_threads, VxBrickGrid** out) {
   if (!vox || !dims || !spacing || !out || !dims[0] || !dims[1] || !dims[2]) {
     g_err = "vxb_build_from_u16: null or empty input";
     return VXB_ERR_INVALID;
@@ -127,7 +150,8 @@ int vxb_build_internal(const uint16_t* vox, const uint32_t dims[3], const float 
   if (n_threads <= 0) n_threads = (int)std::max(1u, std::thread::hardware_concurrency());
   n_threads = std::min(n_threads, 64);
   const size_t nvox = (size_t)dims[0] * dims[1] * dims[2];
-  auto g = new VxBrickGrid();
+  std::unique_ptr<VxBrickGrid> owner(new VxBrickGrid());   // released to *out at the end; freed on any throw
+  VxBrickGrid* g = owner.get();
   // brick.rs:77 (the f32 division + ceil of div_round_up is exact for these magnitudes)
   for (int i = 0; i < 3; ++i) {
     uint32_t b = (uint32_t)std::ceil((float)dims[i] / (float)BRICK);
@@ -135,7 +159,7 @@ int vxb_build_internal(const uint16_t* vox, const uint32_t dims[3], const float 
     g->extent[i] = g->bc[i] * BRICK;
   }
   if (g->bc[0] >= MAXB || g->bc[1] >= MAXB || g->bc[2] >= MAXB) {  // brick.rs:79-81
-    delete g;
+    owner.reset();
     g_err = "Exceeded max brick count";
     return VXB_ERR_TOO_MANY_BRICKS;
   }
@@ -155,7 +179,7 @@ int vxb_build_internal(const uint16_t* vox, const uint32_t dims[3], const float 
     if (hist[i]) { data_max = (uint32_t)i; break; }
   if (max_value == 0) max_value = (uint16_t)data_max;
   if (max_value == 0) {
-    delete g;
+    owner.reset();
     g_err = "vxb_build_from_u16: volume is all zero (raw/max is undefined, dicom.rs:16)";
     return VXB_ERR_INVALID;
   }
@@ -268,7 +292,7 @@ int vxb_build_internal(const uint16_t* vox, const uint32_t dims[3], const float 
     }
   });
   if (ptr_overflow) {
-    delete g;
+    owner.reset();
     g_err = "atlas pointer exceeds 10 bits (brick.rs:31)";
     return VXB_ERR_TOO_MANY_BRICKS;
   }
@@ -301,7 +325,7 @@ int vxb_build_internal(const uint16_t* vox, const uint32_t dims[3], const float 
   g->transform[10] = spacing[2];
   g->transform[15] = 1.0f;
   (void)nvox;
-  *out = g;
+  *out = owner.release();
   return VXB_OK;
 }
 

@@ -13,6 +13,8 @@
 #include <cstdint>
 #include <cstdlib>
 #include <cstring>
+#include <new>
+#include <stdexcept>
 #include <string>
 #include <vector>
 
@@ -139,7 +141,12 @@ const char* parse_file(const uint8_t* data, size_t size, Slice& out) {
       else return "unsupported transfer syntax (only uncompressed little endian)";
     } else if (g == 0x0004 && e == 0x1220) out.is_dicomdir = true;
     else if (g == 0x0028 && e == 0x0002) out.samples = us();
-    else if (g == 0x0028 && e == 0x0008) out.frames = (uint32_t)std::max(1l, atol(str_value(v, len).c_str()));
+    else if (g == 0x0028 && e == 0x0008) {
+      // NumberOfFrames is an IS string: anything outside 1..65535 is rejected by the caller (a crafted count
+      // must not wrap the PixelData length check or ask for an absurd allocation)
+      long nf = atol(str_value(v, len).c_str());
+      out.frames = nf < 1 ? 1u : (nf > 65536 ? 65536u : (uint32_t)nf);
+    }
     else if (g == 0x0028 && e == 0x0010) out.rows = us();
     else if (g == 0x0028 && e == 0x0011) out.cols = us();
     else if (g == 0x0028 && e == 0x0100) out.bits_alloc = us();
@@ -177,10 +184,30 @@ const char* parse_file(const uint8_t* data, size_t size, Slice& out) {
 
 }  // namespace
 
+static int read_dicoms_to_grid_impl(const uint8_t* const* files, const uint64_t* sizes, uint32_t n_files,
+                                    int n_threads, VxBrickGrid** out);
+
+// No C++ exception may cross the C ABI (a Node or Python host would be std::terminate'd): allocation failures of a
+// legitimately huge -- or crafted -- stack come back as an error code like every other failure.
 extern "C" int vxb_read_dicoms_to_grid(const uint8_t* const* files, const uint64_t* sizes, uint32_t n_files,
                                        int n_threads, VxBrickGrid** out) {
   if (!out) return VXB_ERR_INVALID;
   *out = nullptr;
+  try {
+    return read_dicoms_to_grid_impl(files, sizes, n_files, n_threads, out);
+  } catch (const std::bad_alloc&) {
+    vxb_set_error("out of memory while stacking the slices");
+  } catch (const std::exception& e) {
+    vxb_set_error(e.what());
+  } catch (...) {
+    vxb_set_error("unexpected failure while reading the slices");
+  }
+  if (*out) { vxb_free(*out); *out = nullptr; }
+  return VXB_ERR_INVALID;
+}
+
+static int read_dicoms_to_grid_impl(const uint8_t* const* files, const uint64_t* sizes, uint32_t n_files,
+                                    int n_threads, VxBrickGrid** out) {
   if (!files || !sizes || n_files == 0) {
     vxb_set_error("No dicom data collected");  // lib.rs:181
     return VXB_ERR_INVALID;
@@ -202,8 +229,15 @@ extern "C" int vxb_read_dicoms_to_grid(const uint8_t* const* files, const uint64
     if (s.pixel_repr != 0) { vxb_set_error("Currently only unsigned samples are supported"); return VXB_ERR_INVALID; }
     if (!s.have_spacing) { vxb_set_error("Image did not contain pixel spacing information"); return VXB_ERR_INVALID; }
     if (s.bits_stored == 0 || s.bits_stored > 16) { vxb_set_error("bad BitsStored"); return VXB_ERR_INVALID; }
-    size_t want = (size_t)s.cols * s.rows * s.frames * 2;
-    if (s.cols == 0 || s.rows == 0 || s.pixel_bytes < want) { vxb_set_error("PixelData shorter than rows*columns*frames"); return VXB_ERR_INVALID; }
+    if (s.frames > 65535u) { vxb_set_error("NumberOfFrames out of range (1..65535)"); return VXB_ERR_INVALID; }
+    if (s.cols > 65535u || s.rows > 65535u) { vxb_set_error("Rows / Columns out of range"); return VXB_ERR_INVALID; }
+    // cols, rows, frames <= 65535 each: the product is < 2^48 and * 2 cannot wrap a 64-bit size_t
+    const uint64_t want = (uint64_t)s.cols * s.rows * s.frames * 2u;
+    if ((uint64_t)depth + s.frames > 8128u) {   // brick.rs:77-81: at most 1016 bricks = 8128 voxels per axis
+      vxb_set_error("stack deeper than 8128 slices (brick.rs:77-81 brick-count limit)");
+      return VXB_ERR_INVALID;
+    }
+    if (s.cols == 0 || s.rows == 0 || (uint64_t)s.pixel_bytes < want) { vxb_set_error("PixelData shorter than rows*columns*frames"); return VXB_ERR_INVALID; }
     if (depth == 0) { cols = s.cols; rows = s.rows; bits_stored = s.bits_stored; }
     else if (s.cols != cols || s.rows != rows) {                     // buf3d.rs:35-36 assert_eq
       vxb_set_error("slices differ in rows/columns");

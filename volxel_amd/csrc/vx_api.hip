@@ -1,6 +1,8 @@
 // vx_api.hip -- host side of libvolxel_hip.so: the C ABI of include/volxel_hip.h.
 #include <hip/hip_runtime.h>
 
+#include <algorithm>
+#include <chrono>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
@@ -21,6 +23,7 @@ thread_local std::string g_create_error;
 struct EventPair {
   hipEvent_t a, b;
   uint32_t launches = 1;   // frames covered by this interval (pipelined batches cover several)
+  bool merge = false;      // interval of a merge_results launch (reported apart, VxCounters.merge_ms)
 };
 
 }  // namespace
@@ -80,8 +83,19 @@ struct VxContext {
   int order_builds_left = 2;   // rebuild the order after the first frames that follow a change
   VxCounters base{};           // totals folded in when the record array is reallocated
   std::vector<EventPair> free_events, pending_events;
-  double kernel_ms = 0.0, last_kernel_ms = 0.0;
+  double kernel_ms = 0.0, last_kernel_ms = 0.0, merge_ms = 0.0;
   uint64_t launches = 0, frames = 0;
+  uint32_t min_launch_frames = 0, max_launch_frames = 0;   // what the launches since the last reset covered
+  hipStream_t aux_stream = nullptr;   // layout builds of an upload, overlapped with the atlas copy
+  double upload_seconds = 0.0;        // wall time of the last vx_upload_volume (copies + layout build)
+  uint64_t upload_host_bytes = 0;     // host bytes it moved over PCIe
+  int upload_pinned = 0;              // whether the atlas could be pinned in place
+  void note_launch(uint32_t n) {
+    launches += 1;
+    frames += n;
+    min_launch_frames = (min_launch_frames == 0 || n < min_launch_frames) ? n : min_launch_frames;
+    max_launch_frames = n > max_launch_frames ? n : max_launch_frames;
+  }
   int dvr_variant = -1;  // -1: tuned kernel; 0: generic
 
   // frame pipelining (vx_render_frames): independent accumulation frames in flight on their own
@@ -137,9 +151,14 @@ static void drain_events(VxContext* c) {
     (void)hipEventSynchronize(e.b);
     float ms = 0.f;
     if (hipEventElapsedTime(&ms, e.a, e.b) == hipSuccess) {
-      c->kernel_ms += ms;
-      c->last_kernel_ms = ms / (float)(e.launches ? e.launches : 1u);
+      if (e.merge) {
+        c->merge_ms += ms;
+      } else {
+        c->kernel_ms += ms;
+        c->last_kernel_ms = ms / (float)(e.launches ? e.launches : 1u);
+      }
     }
+    e.merge = false;
     c->free_events.push_back(e);
   }
   c->pending_events.clear();
@@ -311,32 +330,29 @@ static int rebuild_skip_mask(VxContext* c) {
 }
 
 
+static void add_record(VxCounters& t, const DevCounters& w) {
+  t.samples += w.samples;
+  t.lane_slots += w.slots;
+  t.rays += w.rays;
+  t.pixels += w.pixels;
+  t.skip_steps += w.skips;
+  t.grad_samples += w.grads;
+  t.gathers += w.gathers;
+  t.lds_reads += w.lds_reads;
+}
+
 static int fold_counters(VxContext* c) {
   if (!c->dc || !c->dc_waves) return VX_OK;
   std::vector<DevCounters> h(c->dc_waves);
   VX_HIP(c, hipMemcpy(h.data(), c->dc, h.size() * sizeof(DevCounters), hipMemcpyDeviceToHost));
-  for (const auto& w : h) {
-    c->base.samples += w.samples;
-    c->base.lane_slots += w.slots;
-    c->base.rays += w.rays;
-    c->base.pixels += w.pixels;
-    c->base.skip_steps += w.skips;
-    c->base.grad_samples += w.grads;
-  }
+  for (const auto& w : h) add_record(c->base, w);
   VX_HIP(c, hipMemset(c->dc, 0, c->dc_waves * sizeof(DevCounters)));
   for (auto& p : c->pipes) {
     if (!p.dc) continue;
-    VX_HIP(c, hipStreamSynchronize(p.stream));
+    if (p.stream) VX_HIP(c, hipStreamSynchronize(p.stream));
     std::vector<DevCounters> hp(c->pipe_waves);
     VX_HIP(c, hipMemcpy(hp.data(), p.dc, hp.size() * sizeof(DevCounters), hipMemcpyDeviceToHost));
-    for (const auto& w : hp) {
-      c->base.samples += w.samples;
-      c->base.lane_slots += w.slots;
-      c->base.rays += w.rays;
-      c->base.pixels += w.pixels;
-      c->base.skip_steps += w.skips;
-      c->base.grad_samples += w.grads;
-    }
+    for (const auto& w : hp) add_record(c->base, w);
     VX_HIP(c, hipMemset(p.dc, 0, c->pipe_waves * sizeof(DevCounters)));
   }
   return VX_OK;
@@ -454,6 +470,7 @@ void vx_destroy(VxContext* c) {
     if (p.done) (void)hipEventDestroy(p.done);
     if (p.merged) (void)hipEventDestroy(p.merged);
   }
+  if (c->aux_stream) (void)hipStreamDestroy(c->aux_stream);
   if (c->own_stream) (void)hipStreamDestroy(c->own_stream);
   delete c;
 }
@@ -468,7 +485,9 @@ int vx_set_stream(VxContext* c, void* s) {
   return VX_OK;
 }
 
-static int build_layout(VxContext* c) {
+// Allocate the device layout the trilinear modes sample (cellquad / brickf32); returns its number of z layers
+// (apron-brick layers / brick layers) through n_layers.  The contents are filled by build_layout_layers.
+static int alloc_layout(VxContext* c, uint32_t& n_layers) {
   if (c->cq_alloc) {
     (void)hipFree(c->cq_alloc);
     c->cq_alloc = nullptr;
@@ -479,13 +498,12 @@ static int build_layout(VxContext* c) {
     c->bf_alloc = nullptr;
     c->dv.bf = nullptr;
   }
+  n_layers = 0;
   if (c->layout == VX_LAYOUT_BRICKF32) {
     uint64_t n_vox = (uint64_t)c->dv.bc[0] * c->dv.bc[1] * c->dv.bc[2] * 512u;
     VX_HIP(c, hipMalloc(&c->bf_alloc, n_vox * sizeof(float)));
     c->dv.bf = (const float*)c->bf_alloc;
-    hipLaunchKernelGGL(build_brickf32, dim3((uint32_t)((n_vox + 255) / 256)), dim3(256), 0, c->stream,
-                       c->dv, (float*)c->bf_alloc, n_vox);
-    VX_HIP(c, hipGetLastError());
+    n_layers = c->dv.bc[2];
     return VX_OK;
   }
   if (c->layout != VX_LAYOUT_CELLQUAD) return VX_OK;
@@ -498,13 +516,61 @@ static int build_layout(VxContext* c) {
             "VX_LAYOUT_REFERENCE with vx_set_layout", (unsigned long long)n_quads);
   VX_HIP(c, hipMalloc(&c->cq_alloc, n_quads * sizeof(float4)));
   c->dv.cq = (const float4*)c->cq_alloc;
-  uint64_t blocks = (n_quads + 255) / 256;
-  if (blocks > 0x7fffffffull) VX_FAIL(c, VX_ERR_INVALID, "volume too large for the cellquad layout");
-  hipLaunchKernelGGL(build_cellquad, dim3((uint32_t)blocks), dim3(256), 0, c->stream, c->dv,
-                     (float4*)c->cq_alloc, n_quads);
+  n_layers = c->dv.cq_bc[2];
+  return VX_OK;
+}
+
+// fill z layers [z0, z1) of the layout on `st` (one thread per quad / voxel; layers are contiguous in both layouts)
+static int build_layout_layers(VxContext* c, uint32_t z0, uint32_t z1, hipStream_t st) {
+  if (z1 <= z0) return VX_OK;
+  if (c->layout == VX_LAYOUT_BRICKF32) {
+    const uint64_t per = (uint64_t)c->dv.bc[0] * c->dv.bc[1] * 512u;
+    const uint64_t first = per * z0, end = per * z1;
+    for (uint64_t at = first; at < end;) {   // <= 2^31 threads per launch
+      uint64_t n = end - at < (1ull << 31) ? end - at : (1ull << 31);
+      hipLaunchKernelGGL(build_brickf32, dim3((uint32_t)((n + 255) / 256)), dim3(256), 0, st, c->dv,
+                         (float*)c->bf_alloc, at, at + n);
+      at += n;
+    }
+  } else if (c->layout == VX_LAYOUT_CELLQUAD) {
+    const uint64_t per = (uint64_t)c->dv.cq_bc[0] * c->dv.cq_bc[1] * CQ_BRICK_QUADS;
+    const uint64_t first = per * z0, end = per * z1;
+    for (uint64_t at = first; at < end;) {
+      uint64_t n = end - at < (1ull << 31) ? end - at : (1ull << 31);
+      hipLaunchKernelGGL(build_cellquad, dim3((uint32_t)((n + 255) / 256)), dim3(256), 0, st, c->dv,
+                         (float4*)c->cq_alloc, at, at + n);
+      at += n;
+    }
+  }
   VX_HIP(c, hipGetLastError());
   return VX_OK;
 }
+
+static int build_layout(VxContext* c) {   // whole layout on the context's stream (vx_set_layout)
+  uint32_t n = 0;
+  int rc = alloc_layout(c, n);
+  if (rc) return rc;
+  return build_layout_layers(c, 0, n, c->stream);
+}
+
+// Pin a caller-owned host range for the duration of an upload so that the copy engine reads it directly at
+// PCIe rate ("pin/upload volumes to HBM", BASELINE north star).  Pageable memory would be staged through the
+// runtime's bounce buffers at a fraction of that.  Failing to pin (already registered, locked-memory limit)
+// is not an error: the copies then go the pageable way.
+struct PinnedRange {
+  void* p = nullptr;
+  bool pinned = false;
+  PinnedRange(const void* ptr, size_t bytes) {
+    if (!ptr || bytes < (1u << 20)) return;
+    p = const_cast<void*>(ptr);
+    hipError_t e = hipHostRegister(p, bytes, hipHostRegisterDefault);
+    pinned = (e == hipSuccess);
+    if (!pinned) (void)hipGetLastError();   // clear the sticky error
+  }
+  ~PinnedRange() {
+    if (pinned) (void)hipHostUnregister(p);
+  }
+};
 
 int vx_upload_volume(VxContext* c, const uint32_t* indirection, const uint32_t ind_size[3],
                      const uint16_t* range, const uint32_t range_size[3], const uint8_t* atlas,
@@ -528,56 +594,134 @@ int vx_upload_volume(VxContext* c, const uint32_t* indirection, const uint32_t i
     VX_FAIL(c, VX_ERR_INVALID, "vx_upload_volume: bad atlas depth");
   size_t atlas_bytes = (size_t)atlas_size[0] * atlas_size[1] * atlas_size[2];
   if (atlas_bytes && !atlas) VX_FAIL(c, VX_ERR_INVALID, "vx_upload_volume: null atlas");
-  VX_HIP(c, hipSetDevice(c->device));
+  for (int k = 0; k < 3; ++k) {
+    if (!mip_data[k] && (size_t)mip_size[k][0] * mip_size[k][1] * mip_size[k][2])
+      VX_FAIL(c, VX_ERR_INVALID, "vx_upload_volume: null mip %d", k);
+    if (mip_size[k][0] != (ind_size[0] >> (k + 1)) || mip_size[k][1] != (ind_size[1] >> (k + 1)) ||
+        mip_size[k][2] != (ind_size[2] >> (k + 1)))
+      VX_FAIL(c, VX_ERR_INVALID, "vx_upload_volume: mip %d has wrong dimensions (brick.rs:156)", k);
+  }
+  const auto t_begin = std::chrono::steady_clock::now();
   VX_HIP(c, hipStreamSynchronize(c->stream));
   free_volume(c);
-  size_t nb = (size_t)ind_size[0] * ind_size[1] * ind_size[2];
-  // every pointer must address an allocated atlas brick
+  const size_t nb = (size_t)ind_size[0] * ind_size[1] * ind_size[2];
+  const size_t per_layer = (size_t)ind_size[0] * ind_size[1];
+  // every pointer must address an allocated atlas brick; while scanning, note how many 8-slice atlas layers
+  // the bricks of each brick z layer reach into (the builder allocates slots in scan order, brick.rs:127-129,
+  // so this grows with z and the layout of early layers can be built while the rest of the atlas still copies)
+  std::vector<uint32_t> reach(ind_size[2], 0u);
   {
-    uint32_t max_slot = atlas_size[2] / 8u;
+    const uint32_t max_slot = atlas_size[2] / 8u;
     for (size_t i = 0; i < nb; ++i) {
       uint32_t p = indirection[i];
-      if ((p & 1023u) >= ind_size[0] || ((p >> 10) & 1023u) >= ind_size[1] ||
-          (((p >> 20) & 1023u) >= max_slot && p != 0))
+      uint32_t az = (p >> 20) & 1023u;
+      if ((p & 1023u) >= ind_size[0] || ((p >> 10) & 1023u) >= ind_size[1] || (az >= max_slot && p != 0))
         VX_FAIL(c, VX_ERR_INVALID, "vx_upload_volume: indirection pointer outside the atlas");
+      uint32_t& r = reach[i / per_layer];
+      if (max_slot && az + 1u > r) r = az + 1u;   // constant bricks alias slot 0 (quirk Q6): also fine
     }
+    for (uint32_t z = 1; z < ind_size[2]; ++z) reach[z] = reach[z] > reach[z - 1] ? reach[z] : reach[z - 1];
   }
-  auto up = [&](const void* src, size_t bytes, void** dst) -> int {
+  auto alloc = [&](size_t bytes, void** dst) -> int {
     *dst = nullptr;
     if (bytes == 0) return VX_OK;
     VX_HIP(c, hipMalloc(dst, bytes));
     c->vol_allocs.push_back(*dst);
-    VX_HIP(c, hipMemcpyAsync(*dst, src, bytes, hipMemcpyHostToDevice, c->stream));
     return VX_OK;
   };
-  void* d = nullptr;
+  void *d_ind = nullptr, *d_range = nullptr, *d_atlas = nullptr, *d_mip[3] = {nullptr, nullptr, nullptr};
   int rc;
-  if ((rc = up(indirection, nb * 4, &d))) return rc;
-  c->dv.indirection = (const uint32_t*)d;
-  if ((rc = up(range, nb * 4, &d))) return rc;  // u16 stream [max,min] == LE u32 (min<<16)|max
-  c->dv.range = (const uint32_t*)d;
-  c->range_host.assign((const uint32_t*)range, (const uint32_t*)range + nb);
-  c->skip_dirty = true;
-  c->order_builds_left = 2;
-  if ((rc = up(atlas, atlas_bytes, &d))) return rc;
-  c->dv.atlas = (const uint8_t*)d;
+  if ((rc = alloc(nb * 4, &d_ind)) || (rc = alloc(nb * 4, &d_range)) || (rc = alloc(atlas_bytes, &d_atlas))) return rc;
+  size_t mip_n[3];
   for (int k = 0; k < 3; ++k) {
-    size_t n = (size_t)mip_size[k][0] * mip_size[k][1] * mip_size[k][2];
-    if (mip_size[k][0] != (ind_size[0] >> (k + 1)) || mip_size[k][1] != (ind_size[1] >> (k + 1)) ||
-        mip_size[k][2] != (ind_size[2] >> (k + 1)))
-      VX_FAIL(c, VX_ERR_INVALID, "vx_upload_volume: mip %d has wrong dimensions (brick.rs:156)", k);
-    if ((rc = up(mip_data[k], n * 4, &d))) return rc;
-    c->dv.mips[k] = (const uint32_t*)d;
+    mip_n[k] = (size_t)mip_size[k][0] * mip_size[k][1] * mip_size[k][2];
+    if ((rc = alloc(mip_n[k] * 4, &d_mip[k]))) return rc;
+    c->dv.mips[k] = (const uint32_t*)d_mip[k];
     for (int i = 0; i < 3; ++i) c->dv.mip_size[k][i] = mip_size[k][i];
   }
+  c->dv.indirection = (const uint32_t*)d_ind;
+  c->dv.range = (const uint32_t*)d_range;   // u16 stream [max,min] == LE u32 (min<<16)|max
+  c->dv.atlas = (const uint8_t*)d_atlas;
   for (int i = 0; i < 3; ++i) {
     c->dv.bc[i] = ind_size[i];
     c->dv.atlas_size[i] = atlas_size[i];
     c->dv.extent[i] = index_extent[i];
   }
-  if ((rc = build_layout(c))) return rc;
-  VX_HIP(c, hipStreamSynchronize(c->stream));  // host buffers may be dropped on return
+  c->range_host.assign((const uint32_t*)range, (const uint32_t*)range + nb);
+  c->skip_dirty = true;
+  c->order_builds_left = 2;
+  uint32_t n_layers = 0;
+  if ((rc = alloc_layout(c, n_layers))) return rc;
+  if (!c->aux_stream) VX_HIP(c, hipStreamCreateWithFlags(&c->aux_stream, hipStreamNonBlocking));
+
+  // ---- copies: metadata first, then the atlas in chunks of whole 8-slice layers from pinned memory;
+  //      the layout layers whose bricks are complete are built on the aux stream behind each chunk
+  PinnedRange pin_atlas(atlas, atlas_bytes), pin_ind(indirection, nb * 4), pin_range(range, nb * 4);
+  VX_HIP(c, hipMemcpyAsync(d_ind, indirection, nb * 4, hipMemcpyHostToDevice, c->stream));
+  VX_HIP(c, hipMemcpyAsync(d_range, range, nb * 4, hipMemcpyHostToDevice, c->stream));
+  for (int k = 0; k < 3; ++k)
+    if (mip_n[k]) VX_HIP(c, hipMemcpyAsync(d_mip[k], mip_data[k], mip_n[k] * 4, hipMemcpyHostToDevice, c->stream));
+  const uint32_t atlas_layers = atlas_size[2] / 8u;
+  const size_t layer_bytes = (size_t)atlas_size[0] * atlas_size[1] * 8u;
+  const uint32_t chunk_layers = layer_bytes ? (uint32_t)std::max<size_t>(1, (16u << 20) / layer_bytes) : 1u;
+  std::vector<hipEvent_t> evs;
+  uint32_t built = 0;     // layout layers launched so far
+  auto buildable = [&](uint32_t copied) {   // layout layers whose source bricks lie in the copied atlas prefix
+    uint32_t z = built;
+    while (z < n_layers) {
+      // cellquad apron layer z reads brick layers z-1 and z; brickf32 layer z reads brick layer z
+      uint32_t top = z < ind_size[2] ? z : ind_size[2] - 1u;
+      if (reach[top] > copied) break;
+      ++z;
+    }
+    return z;
+  };
+  hipError_t le = hipSuccess;
+  for (uint32_t l0 = 0; l0 < atlas_layers && le == hipSuccess; l0 += chunk_layers) {
+    uint32_t l1 = l0 + chunk_layers < atlas_layers ? l0 + chunk_layers : atlas_layers;
+    le = hipMemcpyAsync((char*)d_atlas + l0 * layer_bytes, atlas + l0 * layer_bytes, (l1 - l0) * layer_bytes,
+                        hipMemcpyHostToDevice, c->stream);
+    if (le != hipSuccess) break;
+    uint32_t z1 = buildable(l1);
+    if (z1 > built && l1 < atlas_layers) {   // the last chunk's layers go with the final build below
+      hipEvent_t e;
+      if ((le = hipEventCreateWithFlags(&e, hipEventDisableTiming)) != hipSuccess) break;
+      evs.push_back(e);
+      if ((le = hipEventRecord(e, c->stream)) != hipSuccess) break;
+      if ((le = hipStreamWaitEvent(c->aux_stream, e, 0)) != hipSuccess) break;
+      if ((rc = build_layout_layers(c, built, z1, c->aux_stream))) { le = hipErrorUnknown; break; }
+      built = z1;
+    }
+  }
+  if (le == hipSuccess && built < n_layers) {
+    hipEvent_t e;
+    if ((le = hipEventCreateWithFlags(&e, hipEventDisableTiming)) == hipSuccess) {
+      evs.push_back(e);
+      le = hipEventRecord(e, c->stream);
+      if (le == hipSuccess) le = hipStreamWaitEvent(c->aux_stream, e, 0);
+      if (le == hipSuccess && (rc = build_layout_layers(c, built, n_layers, c->aux_stream))) le = hipErrorUnknown;
+    }
+  }
+  hipError_t s1 = hipStreamSynchronize(c->stream);    // host buffers may be dropped on return
+  hipError_t s2 = hipStreamSynchronize(c->aux_stream);
+  for (hipEvent_t e : evs) (void)hipEventDestroy(e);
+  if (le != hipSuccess || s1 != hipSuccess || s2 != hipSuccess) {
+    hipError_t bad = le != hipSuccess ? le : (s1 != hipSuccess ? s1 : s2);
+    free_volume(c);
+    VX_FAIL(c, VX_ERR_DEVICE, "vx_upload_volume: %s", hipGetErrorString(bad));
+  }
   c->has_volume = true;
+  c->upload_seconds = std::chrono::duration<double>(std::chrono::steady_clock::now() - t_begin).count();
+  c->upload_host_bytes = (uint64_t)atlas_bytes + (uint64_t)nb * 8u + (uint64_t)(mip_n[0] + mip_n[1] + mip_n[2]) * 4u;
+  c->upload_pinned = pin_atlas.pinned ? 1 : 0;
+  return VX_OK;
+}
+
+int vx_upload_stats(VxContext* c, double* seconds, uint64_t* host_bytes, int* pinned) {
+  if (!c) return VX_ERR_INVALID;
+  if (seconds) *seconds = c->upload_seconds;
+  if (host_bytes) *host_bytes = c->upload_host_bytes;
+  if (pinned) *pinned = c->upload_pinned;
   return VX_OK;
 }
 
@@ -817,8 +961,7 @@ int vx_render_frame(VxContext* c, uint32_t frame_index, float sample_weight) {
     le = hipGetLastError();
   }
   c->pending_events.push_back(ev);
-  c->launches++;
-  c->frames++;
+  c->note_launch(1);
   if (le != hipSuccess) VX_FAIL(c, VX_ERR_DEVICE, "render kernel launch: %s", hipGetErrorString(le));
   return VX_OK;
 }
@@ -834,10 +977,7 @@ static int ensure_pipes(VxContext* c, int n) {
       // keep what these records have counted
       std::vector<DevCounters> h(c->pipe_waves);
       if (hipMemcpy(h.data(), p.dc, h.size() * sizeof(DevCounters), hipMemcpyDeviceToHost) == hipSuccess)
-        for (const auto& w : h) {
-          c->base.samples += w.samples; c->base.lane_slots += w.slots; c->base.rays += w.rays;
-          c->base.pixels += w.pixels; c->base.skip_steps += w.skips; c->base.grad_samples += w.grads;
-        }
+        for (const auto& w : h) add_record(c->base, w);
       (void)hipFree(p.dc);
     }
     p.result = nullptr;
@@ -915,12 +1055,17 @@ int vx_render_frames(VxContext* c, uint32_t first_frame, uint32_t count, const f
       VX_HIP(c, hipEventRecord(e2.b, c->stream));   // the render kernel alone; the blend is outside
       c->pending_events.push_back(e2);
       if (le == hipSuccess) {
+        EventPair e3;
+        if ((rc = take_events(c, e3))) return rc;
+        e3.merge = true;
+        VX_HIP(c, hipEventRecord(e3.a, c->stream));
         hipLaunchKernelGGL(merge_results, dim3((nqm + 255) / 256), dim3(256), 0, c->stream, c->slab, ma, nqm);
         le = hipGetLastError();
+        VX_HIP(c, hipEventRecord(e3.b, c->stream));
+        c->pending_events.push_back(e3);
       }
       done += n;
-      c->launches += 1;
-      c->frames += n;
+      c->note_launch(n);
     }
     if (le != hipSuccess) VX_FAIL(c, VX_ERR_DEVICE, "render kernel launch: %s", hipGetErrorString(le));
     return VX_OK;
@@ -949,8 +1094,7 @@ int vx_render_frames(VxContext* c, uint32_t first_frame, uint32_t count, const f
     }
     VX_HIP(c, hipEventRecord(p.merged, c->stream));
     p.has_merged = true;
-    c->launches++;
-    c->frames++;
+    c->note_launch(1);
   }
   VX_HIP(c, hipEventRecord(ev.b, c->stream));
   c->pending_events.push_back(ev);
@@ -1126,6 +1270,11 @@ int vx_get_counters(VxContext* c, VxCounters* out) {
   out->frames = c->frames;
   out->kernel_ms = c->kernel_ms;
   out->last_kernel_ms = c->last_kernel_ms;
+  out->gathers = c->base.gathers;
+  out->lds_reads = c->base.lds_reads;
+  out->merge_ms = c->merge_ms;
+  out->min_launch_frames = c->min_launch_frames;
+  out->max_launch_frames = c->max_launch_frames;
   return VX_OK;
 }
 
@@ -1139,9 +1288,10 @@ int vx_reset_counters(VxContext* c) {
     if (rc) return rc;
   }
   c->base = VxCounters{};
-  c->kernel_ms = c->last_kernel_ms = 0.0;
+  c->kernel_ms = c->last_kernel_ms = c->merge_ms = 0.0;
   c->launches = 0;
   c->frames = 0;
+  c->min_launch_frames = c->max_launch_frames = 0;
   return VX_OK;
 }
 
@@ -1169,6 +1319,100 @@ int vx_debug_build_skip_mask(const uint32_t* range_packed, const uint32_t brick_
   if (level_out) *level_out = (uint32_t)level;
   if (dims_out) { dims_out[0] = md[0]; dims_out[1] = md[1]; dims_out[2] = md[2]; }
   if (bits_out) memcpy(bits_out, bits.data(), bits.size() * 4);
+  return VX_OK;
+}
+
+// test hook: random.glsl on the device
+int vx_debug_rng(VxContext* c, int op, const uint32_t* a, const uint32_t* b, uint32_t n, uint32_t* out) {
+  if (!c || !a || !out || n == 0 || n > 65536u || op < 0 || op > 3 || (op == 0 && !b)) return VX_ERR_INVALID;
+  VX_DEV(c);
+  const uint32_t n_in = op < 2 ? n : 1u;
+  uint32_t *da = nullptr, *db = nullptr, *dout = nullptr;
+  hipError_t e = hipMalloc(&da, (size_t)n_in * 4);
+  if (e == hipSuccess) e = hipMalloc(&db, (size_t)n_in * 4);
+  if (e == hipSuccess) e = hipMalloc(&dout, (size_t)n * 4);
+  if (e == hipSuccess) e = hipMemcpyAsync(da, a, (size_t)n_in * 4, hipMemcpyHostToDevice, c->stream);
+  if (e == hipSuccess && op == 0) e = hipMemcpyAsync(db, b, (size_t)n_in * 4, hipMemcpyHostToDevice, c->stream);
+  if (e == hipSuccess) {
+    hipLaunchKernelGGL(debug_rng, dim3((n + 255) / 256), dim3(256), 0, c->stream, op, da, db, n, dout);
+    e = hipGetLastError();
+  }
+  if (e == hipSuccess) e = hipMemcpyAsync(out, dout, (size_t)n * 4, hipMemcpyDeviceToHost, c->stream);
+  if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
+  (void)hipFree(da);
+  (void)hipFree(db);
+  (void)hipFree(dout);
+  if (e != hipSuccess) VX_FAIL(c, VX_ERR_DEVICE, "vx_debug_rng: %s", hipGetErrorString(e));
+  return VX_OK;
+}
+
+// measurement hook: L1 gather rate for a given number of distinct lines per gather instruction
+int vx_probe_gather_rate(VxContext* c, uint32_t lines, double* clk_out, uint32_t* clock_khz_out) {
+  if (!c || !clk_out || lines < 1u || lines > 64u) return VX_ERR_INVALID;
+  VX_DEV(c);
+  float4* table = nullptr;
+  float* sink = nullptr;
+  hipEvent_t e0 = nullptr, e1 = nullptr;
+  hipError_t e = hipMalloc(&table, 128u * 128u);   // 128 lines = 16 KiB: L1 resident
+  if (e == hipSuccess) e = hipMalloc(&sink, 4);
+  if (e == hipSuccess) e = hipMemsetAsync(table, 0, 128u * 128u, c->stream);
+  if (e == hipSuccess) e = hipEventCreate(&e0);
+  if (e == hipSuccess) e = hipEventCreate(&e1);
+  const int cus = c->prop.multiProcessorCount, iters = 512, blocks = cus * 5;   // 20 waves per CU
+  float ms = 0.f;
+  for (int rep = 0; rep < 3 && e == hipSuccess; ++rep) {   // the last repetition is the one reported
+    e = hipEventRecord(e0, c->stream);
+    hipLaunchKernelGGL(probe_gather_rate, dim3(blocks), dim3(256), 0, c->stream, table, lines, iters, sink);
+    if (e == hipSuccess) e = hipGetLastError();
+    if (e == hipSuccess) e = hipEventRecord(e1, c->stream);
+    if (e == hipSuccess) e = hipEventSynchronize(e1);
+    if (e == hipSuccess) e = hipEventElapsedTime(&ms, e0, e1);
+  }
+  if (e0) (void)hipEventDestroy(e0);
+  if (e1) (void)hipEventDestroy(e1);
+  (void)hipFree(table);
+  (void)hipFree(sink);
+  if (e != hipSuccess) VX_FAIL(c, VX_ERR_DEVICE, "vx_probe_gather_rate: %s", hipGetErrorString(e));
+  const double khz = (double)c->prop.clockRate;
+  const double gathers_per_cu = (double)blocks * 4.0 * iters * 8.0 / cus;
+  *clk_out = (ms * 1e-3 * khz * 1e3) / gathers_per_cu;
+  if (clock_khz_out) *clock_khz_out = (uint32_t)c->prop.clockRate;
+  return VX_OK;
+}
+
+// measurement hook: distinct lines per gather of the tuned cellquad DVR march (one frame, nothing is stored)
+int vx_probe_gather_spread(VxContext* c, uint32_t frame_index, uint64_t out3[3]) {
+  if (!c || !out3) return VX_ERR_INVALID;
+  VX_DEV(c);
+  dim3 grid;
+  int rc = prepare_render(c, grid);
+  if (rc) return rc;
+  if (!(is_tuned(c) && c->layout == VX_LAYOUT_CELLQUAD))
+    VX_FAIL(c, VX_ERR_INVALID, "vx_probe_gather_spread: needs render_mode dvr on the cellquad layout");
+  const size_t waves = (size_t)grid.x * 4u;
+  DevCounters* d = nullptr;
+  VX_HIP(c, hipMalloc(&d, waves * sizeof(DevCounters)));
+  hipError_t e = hipMemsetAsync(d, 0, waves * sizeof(DevCounters), c->stream);
+  MultiOut mo{};
+  mo.count = 1;
+  mo.out[0] = c->slab;   // never written by the probe build
+  mo.dc[0] = d;
+  mo.frame[0] = frame_index;
+  if (e == hipSuccess) {
+    launch_dvr_cq_multi(c->params, c->dv, c->tf, c->tf_len, mo, 0.0f, c->tm, c->stream, nullptr, true);
+    e = hipGetLastError();
+  }
+  std::vector<DevCounters> h(waves);
+  if (e == hipSuccess) e = hipMemcpyAsync(h.data(), d, waves * sizeof(DevCounters), hipMemcpyDeviceToHost, c->stream);
+  if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
+  (void)hipFree(d);
+  if (e != hipSuccess) VX_FAIL(c, VX_ERR_DEVICE, "vx_probe_gather_spread: %s", hipGetErrorString(e));
+  out3[0] = out3[1] = out3[2] = 0;
+  for (const auto& w : h) {
+    out3[0] += w.gathers / 2u;   // q0 gathers (q1 repeats the pattern one slice further)
+    out3[1] += w.rays;           // wave-wide distinct lines, summed over the q0 gathers
+    out3[2] += w.pixels;         // look-ups of the 16 lane quads, summed over the q0 gathers
+  }
   return VX_OK;
 }
 

@@ -389,6 +389,12 @@ VXD Ray setup_world_ray(const VxParams& p, float tex_x, float tex_y, float rx, f
   float y_off = fma_(ry, 2.0f, -1.0f) * (1.0f / (float)p.res[1]);
   float sx = tex_x + x_off, sy = tex_y + y_off;
   float cw[4], vp[4], wp[4];
+  if (p.camera_ortho) {  // [build] parallel rays: near-plane point of the pixel, camera -z axis (wave uniform)
+    mat4_mul(p.camera_proj_inv, fma_(sx, 2.0f, -1.0f), fma_(sy, 2.0f, -1.0f), -1.0f, 1.0f, vp);
+    mat4_mul(p.camera_view_inv, vp[0] / vp[3], vp[1] / vp[3], vp[2] / vp[3], 1.0f, wp);
+    mat4_mul(p.camera_view_inv, 0.0f, 0.0f, -1.0f, 0.0f, cw);
+    return Ray{v3(wp[0] / wp[3], wp[1] / wp[3], wp[2] / wp[3]), normalize3(v3(cw[0], cw[1], cw[2]))};
+  }
   mat4_mul(p.camera_view_inv, 0.0f, 0.0f, 0.0f, 1.0f, cw);
   V3 cam = v3(cw[0] / cw[3], cw[1] / cw[3], cw[2] / cw[3]);
   mat4_mul(p.camera_proj_inv, fma_(sx, 2.0f, -1.0f), fma_(sy, 2.0f, -1.0f), 0.0f, 1.0f, vp);

@@ -72,7 +72,12 @@ VXD void dvr_store(const VxParams& p, const DevVolume& dv, const DvrRay& r, floa
 // lane whose last sample of a batch was empty jumps to one step before the exit of that macro
 // cell.  Every jumped-over sample lies inside the same empty macro cell, so the set of evaluated
 // samples is exactly "samples whose macro cell is not empty" -- what the oracle counts.
-template <int U, bool SKIP>
+// PROBE = measurement build (vx_probe_gather_spread): the same march, but every gather also counts the distinct
+// 128-byte lines its 64 lane addresses fall into -- over the whole wave and per group of 4 consecutive lanes (the
+// unit the L1 tag pipe works on) -- and nothing is written to the framebuffer.  The sums go to rays / pixels of
+// the counter record (spread[0] = wave-wide lines, spread[1] = quad look-ups; per q0 gather, q1 is the same
+// pattern one slice further).
+template <int U, bool SKIP, bool PROBE = false>
 __global__ __launch_bounds__(256) void render_dvr_cq(const VxParams p, const DevVolume v,
                                                       const float4* __restrict__ tf_global,
                                                       uint32_t tf_len, const MultiOut mo, float weight,
@@ -118,7 +123,8 @@ __global__ __launch_bounds__(256) void render_dvr_cq(const VxParams p, const Dev
   const float inv_dt = SKIP ? 1.0f / r.dt : 0.0f;
 
   float Cx = 0.f, Cy = 0.f, Cz = 0.f, T = 1.0f, tau = 0.0f, kf = 0.0f;  // kf: per-lane step index
-  uint32_t n_samples = 0, n_slots = 0, n_skipped = 0;                   // wave-uniform
+  uint32_t n_samples = 0, n_slots = 0, n_skipped = 0, n_batches = 0;    // wave-uniform
+  uint32_t spread_wave = 0, spread_quad = 0;                            // PROBE only
 
   while (true) {
     {
@@ -126,6 +132,7 @@ __global__ __launch_bounds__(256) void render_dvr_cq(const VxParams p, const Dev
       alive = alive && (t < r.far) && (kf < max_steps_f);
       if (__ballot(alive) == 0ull) break;
     }
+    n_batches += 1u;
     // ---- phase 1: addresses + gathers of U consecutive steps --------------------------------
     float4 q0[U], q1[U];
     float fx[U], fy[U], fz[U];
@@ -171,6 +178,21 @@ __global__ __launch_bounds__(256) void render_dvr_cq(const VxParams p, const Dev
       const float4* qp = cq + o;
       q0[u] = qp[0];
       q1[u] = qp[cq_next_slice(cz)];
+      if (PROBE) {
+        const uint32_t line = o >> 3;  // 8 quads of 16 bytes per 128-byte line
+        unsigned long long rem = ~0ull;
+        while (rem) {
+          uint32_t first = (uint32_t)__builtin_ctzll(rem);
+          uint32_t val = (uint32_t)__shfl((int)line, (int)first, 64);
+          rem &= ~__ballot(line == val);
+          spread_wave += 1u;
+        }
+        const uint32_t qb = lane & ~3u, kq = lane & 3u;
+        uint32_t l0 = (uint32_t)__shfl((int)line, (int)qb, 64), l1 = (uint32_t)__shfl((int)line, (int)(qb + 1u), 64),
+                 l2 = (uint32_t)__shfl((int)line, (int)(qb + 2u), 64);
+        bool first_in_quad = !((kq > 0u && line == l0) || (kq > 1u && line == l1) || (kq > 2u && line == l2));
+        spread_quad += (uint32_t)__builtin_popcountll(__ballot(first_in_quad));
+      }
     }
     // ---- phase 2: interpolate, classify, composite in order -- straight-line code: a lane that
     // does not contribute (finished, skipped, alpha == 0, out of the sample range) runs the same
@@ -224,9 +246,13 @@ __global__ __launch_bounds__(256) void render_dvr_cq(const VxParams p, const Dev
     }
   }
 
+  if (PROBE) {
+    add_counts(dc, n_samples, spread_wave, spread_quad, n_skipped, 0u, n_slots, blk, n_batches * (uint32_t)(2 * U));
+    return;
+  }
   if (in_image) dvr_store(p, v, r, Cx, Cy, Cz, T, weight, slab, si);
   const uint32_t n_px = (uint32_t)__builtin_popcountll(__ballot(in_image));
-  add_counts(dc, n_samples, n_rays, n_px, n_skipped, 0u, n_slots, blk);
+  add_counts(dc, n_samples, n_rays, n_px, n_skipped, 0u, n_slots, blk, n_batches * (uint32_t)(2 * U));
 }
 
 VXD int wave_min_i32(int v) {
@@ -440,7 +466,7 @@ __global__ __launch_bounds__(256) void render_dvr_dp(const VxParams p, const Dev
 
 inline void launch_dvr_cq_multi(const VxParams& p, const DevVolume& v, const float4* tf, uint32_t tf_len,
                                 const MultiOut& mo, float weight, const TileMap& tm, hipStream_t stream,
-                                const uint32_t* order);
+                                const uint32_t* order, bool probe = false);
 
 inline void launch_dvr_cq(const VxParams& p, const DevVolume& v, const float4* tf, uint32_t tf_len,
                           float4* slab, uint32_t frame, float weight, const TileMap& tm,
@@ -455,7 +481,7 @@ inline void launch_dvr_cq(const VxParams& p, const DevVolume& v, const float4* t
 
 inline void launch_dvr_cq_multi(const VxParams& p, const DevVolume& v, const float4* tf, uint32_t tf_len,
                                 const MultiOut& mo, float weight, const TileMap& tm, hipStream_t stream,
-                                const uint32_t* order) {
+                                const uint32_t* order, bool probe) {
   float4* slab = mo.out[0];
   DevCounters* dc = mo.dc[0];
   const uint32_t frame = mo.frame[0];
@@ -464,7 +490,7 @@ inline void launch_dvr_cq_multi(const VxParams& p, const DevVolume& v, const flo
   // depth-parallel waves only on request (VX_DVR_DP=1): they cut the longest dependent chain 8x
   // (8 shards: 0.19 ms instead of 0.28 ms per GPU) but cost ~1.6x the instructions (0.80 vs 0.51 ms
   // on one GPU) and re-associate the colour sum, which gives up bit-identity across shard counts
-  if (dp == 1) {
+  if (dp == 1 && !probe) {
     dim3 grid(groups * 1024u), block(256);
     const bool skip = p.dvr_skip_empty && v.skip_bits;
     size_t lds = (size_t)tf_len * sizeof(float4) + (skip ? (size_t)v.skip_words * 4u : 0u);
@@ -480,6 +506,13 @@ inline void launch_dvr_cq_multi(const VxParams& p, const DevVolume& v, const flo
   size_t lds = (size_t)tf_len * sizeof(float4) + (skip ? (size_t)v.skip_words * 4u : 0u);
 #define VX_LAUNCH(UU, SS) \
   hipLaunchKernelGGL((render_dvr_cq<UU, SS>), grid, block, lds, stream, p, v, tf, tf_len, mo, weight, tm, order)
+  if (probe) {
+    if (skip)
+      hipLaunchKernelGGL((render_dvr_cq<4, true, true>), grid, block, lds, stream, p, v, tf, tf_len, mo, weight, tm, order);
+    else
+      hipLaunchKernelGGL((render_dvr_cq<4, false, true>), grid, block, lds, stream, p, v, tf, tf_len, mo, weight, tm, order);
+    return;
+  }
   if (skip) {
     switch (unroll) {
       case 1: VX_LAUNCH(1, true); break;

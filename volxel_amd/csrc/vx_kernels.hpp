@@ -65,17 +65,22 @@ struct DevCounters {
   unsigned long long samples, slots;
   uint32_t rays, pixels, skips, grads;
   uint32_t last_slots;  // lane slots of the most recent launch: the cost fed back to build_order
+  uint32_t gathers;     // 16-byte-per-lane gather wave instructions issued (tuned DVR kernels)
+  uint32_t lds_reads;   // LDS tap-read wave instructions (LDS-tile kernels)
   uint32_t pad;
 };
 
 // `block` = logical block id (identical to blockIdx.x unless the launch is permuted by `order`)
 VXD void add_counts(DevCounters* dc, uint32_t samples, uint32_t rays, uint32_t pixels, uint32_t skips,
-                    uint32_t grads, uint32_t slots, uint32_t block = 0xffffffffu) {
+                    uint32_t grads, uint32_t slots, uint32_t block = 0xffffffffu, uint32_t gathers = 0u,
+                    uint32_t lds_reads = 0u) {
   if ((threadIdx.x & 63u) == 0) {
     if (block == 0xffffffffu) block = blockIdx.x;
     DevCounters* w = dc + (block * (blockDim.x >> 6) + (threadIdx.x >> 6));
     DevCounters c = *w;
     c.last_slots = slots;
+    c.gathers += gathers;
+    c.lds_reads += lds_reads;
     c.samples += samples;
     c.slots += slots;
     c.rays += rays;
@@ -230,10 +235,12 @@ __global__ __launch_bounds__(1024) void build_order(const DevCounters* __restric
 
 // ---- reference layout -> cellquad (runs once per upload) -------------------------------
 // one thread per stored quad: brick' b, slice lz in [0,9), cell (ly,lx).
+// [first, end) = the quads of a range of apron-brick z layers (the upload builds the layers of an atlas chunk
+// while the next chunk is still crossing PCIe)
 __global__ __launch_bounds__(256) void build_cellquad(const DevVolume v, float4* __restrict__ out,
-                                                       uint64_t n_quads) {
-  uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= n_quads) return;
+                                                       uint64_t first, uint64_t end) {
+  uint64_t i = first + (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= end) return;
   uint32_t q = (uint32_t)(i % CQ_BRICK_QUADS);
   uint64_t b = i / CQ_BRICK_QUADS;
   uint32_t bx = (uint32_t)(b % v.cq_bc[0]);
@@ -253,9 +260,9 @@ __global__ __launch_bounds__(256) void build_cellquad(const DevVolume v, float4*
 
 // reference layout -> brickf32: one thread per voxel of the padded grid
 __global__ __launch_bounds__(256) void build_brickf32(const DevVolume v, float* __restrict__ out,
-                                                       uint64_t n_vox) {
-  uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= n_vox) return;
+                                                       uint64_t first, uint64_t end) {
+  uint64_t i = first + (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= end) return;
   uint32_t l = (uint32_t)(i & 511u);
   uint64_t b = i >> 9;
   uint32_t bx = (uint32_t)(b % v.bc[0]);
@@ -379,5 +386,54 @@ __global__ __launch_bounds__(256) void build_importance_quads(const float* __res
 
 // test hook: the unorm8 table
 __global__ void unorm_table(float* out) { out[threadIdx.x] = unorm8(threadIdx.x); }
+
+// test hook (vx_debug_rng): random.glsl:41-106 evaluated on the device, one thread per output word
+__global__ __launch_bounds__(256) void debug_rng(int op, const uint32_t* __restrict__ a, const uint32_t* __restrict__ b,
+                                                  uint32_t n, uint32_t* __restrict__ out) {
+  uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  if (op == 0) {
+    out[i] = tea32(a[i], b[i]);
+  } else if (op == 1) {
+    out[i] = wang_hash(a[i]);
+  } else {
+    Rng s = seed_xoshiro(a[0]);
+    uint32_t w = 0;
+    float f = 0.0f;
+    for (uint32_t k = 0; k <= i; ++k) {  // thread i walks the stream to its word (n is small)
+      if (op == 2) w = xoshiro_next(s);
+      else f = rng(s);
+    }
+    out[i] = op == 2 ? w : __builtin_bit_cast(uint32_t, f);
+  }
+}
+
+// measurement hook (vx_probe_gather_rate): nothing but 16-byte-per-lane gathers whose 64 lane addresses fall
+// into `lines` distinct 128-byte lines of a 16 KiB (L1-resident) table; 8 gathers in flight per wave
+__device__ inline uint32_t probe_hash(uint32_t x) {
+  x ^= x >> 16; x *= 0x7feb352du; x ^= x >> 15; x *= 0x846ca68bu; x ^= x >> 16;
+  return x;
+}
+__global__ __launch_bounds__(256) void probe_gather_rate(const float4* __restrict__ base, uint32_t lines, int iters,
+                                                          float* __restrict__ out) {
+  const uint32_t lane = threadIdx.x & 63u, wave = blockIdx.x * 4u + (threadIdx.x >> 6);
+  const uint32_t g = (lane * lines) >> 6;                      // group of lanes sharing one line
+  const uint32_t first = (g * 64u + lines - 1u) / lines;       // first lane of the group
+  const uint32_t within = (lane - first) & 7u;                 // quad inside the line
+  float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+  uint32_t s = probe_hash(wave * 977u + 13u);
+  for (int it = 0; it < iters; ++it) {
+    float4 q[8];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) {
+      s = s * 1664525u + 1013904223u;                           // wave-uniform stream
+      uint32_t line = ((s >> 8) + g * 37u) & 127u;              // distinct per group: 37 is odd
+      q[u] = base[(line << 3) + within];
+    }
+#pragma unroll
+    for (int u = 0; u < 8; ++u) { acc.x += q[u].x; acc.y += q[u].y; acc.z += q[u].z; acc.w += q[u].w; }
+  }
+  if (acc.x + acc.y + acc.z + acc.w == 12345.678f) out[0] = acc.x;
+}
 
 }  // namespace vx

@@ -81,6 +81,10 @@ const M = {
     const f = 1 / Math.tan(fovy / 2), nf = 1 / (near - far);
     return [f / aspect, 0, 0, 0, 0, f, 0, 0, 0, 0, (far + near) * nf, -1, 0, 0, 2 * far * near * nf, 0];
   },
+  ortho(left, right, bottom, top, near, far) { // gl-matrix mat4.ortho; [build]: the reference camera is perspective only
+    const lr = 1 / (left - right), bt = 1 / (bottom - top), nf = 1 / (near - far);
+    return [-2 * lr, 0, 0, 0, 0, -2 * bt, 0, 0, 0, 0, 2 * nf, 0, (left + right) * lr, (top + bottom) * bt, (far + near) * nf, 1];
+  },
   invert(m) { // Gauss-Jordan with partial pivoting on the 4x4
     const a = [0, 1, 2, 3].map(r => [m[r], m[4 + r], m[8 + r], m[12 + r], +(r === 0), +(r === 1), +(r === 2), +(r === 3)]);
     for (let c = 0; c < 4; ++c) {
@@ -122,9 +126,16 @@ function generateTransferFunction(colors, generatedSteps = 128) {
 }
 
 class Camera { // representation/scene.ts
-  constructor(distance = 1) { this.view = [0, 0, 0]; this.pos = [0, 0, -distance]; }
+  // orthoHalfHeight ([build], BASELINE config 1): null = the reference's perspective camera
+  constructor(distance = 1) { this.view = [0, 0, 0]; this.pos = [0, 0, -distance]; this.orthoHalfHeight = null; }
   viewMatrix() { return M.lookAt(this.pos, this.view, [0, 1, 0]); }
-  projMatrix(aspect, fov = Math.PI / 3) { return M.perspective(fov, aspect, 0.1, 1000); }
+  projMatrix(aspect, fov = Math.PI / 3) {
+    if (this.orthoHalfHeight !== null) {
+      const h = this.orthoHalfHeight;
+      return M.ortho(-h * aspect, h * aspect, -h, h, 0.1, 1000);
+    }
+    return M.perspective(fov, aspect, 0.1, 1000);
+  }
 }
 
 /** representation/environment.ts: base map = width x height RGBA floats, row 0 = TOP */
@@ -263,6 +274,7 @@ class Volxel3DDicomRenderer {
     const view = this.camera.viewMatrix(), proj = this.camera.projMatrix(this.width / this.height);
     p.set('camera_view', view); p.set('camera_proj', proj);
     p.set('camera_view_inv', M.invert(M.f32(view))); p.set('camera_proj_inv', M.invert(M.f32(proj)));
+    p.set('camera_ortho', this.camera.orthoHalfHeight !== null ? 1 : 0);
     const combined = M.mul(this.volume.transform, this.volume.grid.transform); // volume.ts:14-16
     const e = this.volume.grid.indexExtent;
     const lo = M.apply(combined, [0, 0, 0, 1]), hi = M.apply(combined, [e[0], e[1], e[2], 1]);

@@ -36,14 +36,33 @@ static int get_args(napi_env env, napi_callback_info info, size_t n, napi_value*
   return 1;
 }
 
-static VxContext* get_ctx(napi_env env, napi_value v) {
+/* The JS handle wraps a small box, not the context itself: destroy() empties the box, so a call made after
+ * dispose() (or a second destroy) finds NULL and throws instead of touching freed memory. */
+typedef struct Handle {
+  VxContext* ctx;
+} Handle;
+
+static Handle* get_handle(napi_env env, napi_value v) {
   void* p = NULL;
   if (napi_get_value_external(env, v, &p) != napi_ok || !p) {
     napi_throw_type_error(env, NULL, "volxel_napi: expected a context handle");
     return NULL;
   }
-  return (VxContext*)p;
+  return (Handle*)p;
 }
+
+static VxContext* get_ctx(napi_env env, napi_value v) {
+  Handle* h = get_handle(env, v);
+  if (!h) return NULL;
+  if (!h->ctx) {
+    napi_throw_error(env, NULL, "volxel_napi: the context has been destroyed");
+    return NULL;
+  }
+  return h->ctx;
+}
+
+/* number of elements of [x, y, z] multiplied out, saturating */
+static uint64_t prod3(const uint32_t v[3]) { return (uint64_t)v[0] * v[1] * v[2]; }
 
 /* typed array -> pointer + element count (+ checks the element type) */
 static int typed(napi_env env, napi_value v, napi_typedarray_type want, void** data, size_t* len) {
@@ -76,8 +95,10 @@ static napi_value prop(napi_env env, napi_value obj, const char* name) {
 
 static void ctx_finalize(napi_env env, void* data, void* hint) {
   (void)env; (void)hint;
-  /* contexts are destroyed explicitly (destroy()); nothing to do for a dangling handle */
-  (void)data;
+  Handle* h = (Handle*)data;
+  if (!h) return;
+  if (h->ctx) vx_destroy(h->ctx); /* a handle dropped without destroy() still releases the device memory */
+  free(h);
 }
 
 /* create(deviceId) -> handle */
@@ -88,16 +109,29 @@ static napi_value n_create(napi_env env, napi_callback_info info) {
   NAPI_OK(napi_get_value_int32(env, a[0], &dev));
   VxContext* c = NULL;
   if (vx_create(dev, &c) != VX_OK) return throw_msg(env, vx_last_error(NULL));
+  Handle* box = (Handle*)malloc(sizeof(Handle));
+  if (!box) {
+    vx_destroy(c);
+    return throw_msg(env, "volxel_napi: out of memory");
+  }
+  box->ctx = c;
   napi_value h;
-  NAPI_OK(napi_create_external(env, c, ctx_finalize, NULL, &h));
+  if (napi_create_external(env, box, ctx_finalize, NULL, &h) != napi_ok) {
+    vx_destroy(c);
+    free(box);
+    return throw_msg(env, "volxel_napi: napi_create_external failed");
+  }
   return h;
 }
 
+/* destroy(handle): idempotent */
 static napi_value n_destroy(napi_env env, napi_callback_info info) {
   napi_value a[1];
   if (!get_args(env, info, 1, a)) return NULL;
-  VxContext* c = get_ctx(env, a[0]);
-  if (c) vx_destroy(c);
+  Handle* h = get_handle(env, a[0]);
+  if (!h) return NULL;
+  if (h->ctx) vx_destroy(h->ctx);
+  h->ctx = NULL;
   return NULL;
 }
 
@@ -109,14 +143,18 @@ static napi_value n_upload_volume(napi_env env, napi_callback_info info) {
   if (!c) return NULL;
   napi_value m = a[1];
   void *ind, *rng, *atl;
-  size_t n;
+  size_t n, n_ind, n_rng, n_atl;
   uint32_t is[3], rs[3], as[3], ext[3];
-  if (!typed(env, prop(env, m, "indirection"), napi_uint32_array, &ind, &n)) return NULL;
-  if (!typed(env, prop(env, m, "range"), napi_uint16_array, &rng, &n)) return NULL;
-  if (!typed(env, prop(env, m, "atlas"), napi_uint8_array, &atl, &n)) return NULL;
+  if (!typed(env, prop(env, m, "indirection"), napi_uint32_array, &ind, &n_ind)) return NULL;
+  if (!typed(env, prop(env, m, "range"), napi_uint16_array, &rng, &n_rng)) return NULL;
+  if (!typed(env, prop(env, m, "atlas"), napi_uint8_array, &atl, &n_atl)) return NULL;
   if (!u32x3(env, prop(env, m, "indirectionSize"), is) || !u32x3(env, prop(env, m, "rangeSize"), rs) ||
       !u32x3(env, prop(env, m, "atlasSize"), as) || !u32x3(env, prop(env, m, "indexExtent"), ext))
     return NULL;
+  /* the C ABI takes raw pointers: the typed arrays must really hold what the size fields promise */
+  if ((uint64_t)n_ind < prod3(is)) return throw_msg(env, "uploadVolume: indirection shorter than indirectionSize");
+  if ((uint64_t)n_rng < 2u * prod3(rs)) return throw_msg(env, "uploadVolume: range shorter than 2 * rangeSize");
+  if ((uint64_t)n_atl < prod3(as)) return throw_msg(env, "uploadVolume: atlas shorter than atlasSize");
   napi_value mips = prop(env, m, "rangeMipmaps");
   uint32_t nm = 0;
   NAPI_OK(napi_get_array_length(env, mips, &nm));
@@ -130,6 +168,7 @@ static napi_value n_upload_volume(napi_env env, napi_callback_info info) {
     if (!typed(env, prop(env, e, "mipmap"), napi_uint16_array, &d, &n)) return NULL;
     mp[k] = (const uint16_t*)d;
     if (!u32x3(env, prop(env, e, "stride"), ms[k])) return NULL;
+    if ((uint64_t)n < 2u * prod3(ms[k])) return throw_msg(env, "uploadVolume: range mipmap shorter than 2 * stride");
   }
   if (vx_upload_volume(c, (const uint32_t*)ind, is, (const uint16_t*)rng, rs, (const uint8_t*)atl, as, (int)nm, mp,
                        (const uint32_t(*)[3])ms, ext) != VX_OK)
@@ -377,7 +416,9 @@ static napi_value n_get_counters(napi_env env, napi_callback_info info) {
   NAPI_OK(napi_set_named_property(env, o, name, v));
   PUT("samples", k.samples) PUT("rays", k.rays) PUT("pixels", k.pixels) PUT("skipSteps", k.skip_steps)
   PUT("gradSamples", k.grad_samples) PUT("laneSlots", k.lane_slots) PUT("launches", k.launches) PUT("frames", k.frames)
-  PUT("kernelMs", k.kernel_ms) PUT("lastKernelMs", k.last_kernel_ms)
+  PUT("kernelMs", k.kernel_ms) PUT("lastKernelMs", k.last_kernel_ms) PUT("gathers", k.gathers)
+  PUT("ldsReads", k.lds_reads) PUT("mergeMs", k.merge_ms) PUT("minLaunchFrames", k.min_launch_frames)
+  PUT("maxLaunchFrames", k.max_launch_frames)
 #undef PUT
   return o;
 }

@@ -60,6 +60,7 @@ def compute_params(settings: ViewerSettings, camera: Camera, volume: Volume, den
     put("camera_proj", flat(proj))
     put("camera_view_inv", flat(np.linalg.inv(view32)))   # inverse(camera_view), utils.glsl:24
     put("camera_proj_inv", flat(np.linalg.inv(proj32)))   # inverse(camera_proj), utils.glsl:29
+    p.camera_ortho = 1 if camera.ortho_half_height is not None else 0   # [build] BASELINE config 1
 
     mn, maj = volume.min_maj()
     lo, hi = volume.aabb_clipped(settings.volume_clip_min, settings.volume_clip_max)
@@ -209,6 +210,17 @@ class Volxel3DRenderer:
         atl = np.ascontiguousarray(grid.atlas, dtype=np.uint8)
         n = len(grid.range_mipmaps)
         mips = [np.ascontiguousarray(m, dtype=np.uint16) for m, _ in grid.range_mipmaps]
+        # the C ABI takes raw pointers and cannot check lengths: the arrays must hold what the size fields say
+        prod = lambda t: int(t[0]) * int(t[1]) * int(t[2])
+        if ind.size < prod(grid.indirection_size):
+            raise VolxelError("setup_from_grid: indirection shorter than indirection_size")
+        if rng.size < 2 * prod(grid.range_size):
+            raise VolxelError("setup_from_grid: range shorter than 2 * range_size")
+        if atl.size < prod(grid.atlas_size):
+            raise VolxelError("setup_from_grid: atlas shorter than atlas_size")
+        for m, (_, st) in zip(mips, grid.range_mipmaps):
+            if m.size < 2 * prod(st):
+                raise VolxelError("setup_from_grid: range mipmap shorter than 2 * stride")
         mip_ptrs = (C.c_void_p * max(n, 1))(*[m.ctypes.data for m in mips])
         mip_sizes = (C.c_uint32 * (3 * max(n, 1)))(*[int(x) for _, s in grid.range_mipmaps for x in s])
         self._check(self._lib.vx_upload_volume(
@@ -444,6 +456,27 @@ class Volxel3DRenderer:
 
     def set_layout(self, layout: int):
         self._check(self._lib.vx_set_layout(self._ctx, int(layout)))
+
+    def upload_stats(self):
+        """(seconds, host bytes, pinned) of the last volume upload: copies from pinned host memory in chunks,
+        device-side layout build overlapped behind them (viewer.ts:1106-1142 is its texImage3D counterpart)"""
+        s, b, pin = C.c_double(), C.c_uint64(), C.c_int()
+        self._check(self._lib.vx_upload_stats(self._ctx, C.byref(s), C.byref(b), C.byref(pin)))
+        return s.value, b.value, bool(pin.value)
+
+    def probe_gather_rate(self, lines: int):
+        """clocks per 16-byte-per-lane gather instruction per CU (nominal clock) when the 64 lane addresses
+        fall into `lines` L1-resident lines, and the nominal clock in kHz"""
+        clk, khz = C.c_double(), C.c_uint32()
+        self._check(self._lib.vx_probe_gather_rate(self._ctx, int(lines), C.byref(clk), C.byref(khz)))
+        return clk.value, khz.value
+
+    def probe_gather_spread(self, frame_index: int = 0):
+        """(q0 gather instructions, wave-wide distinct lines, quad line look-ups) of one DVR frame"""
+        out = (C.c_uint64 * 3)()
+        self.bind_uniforms()
+        self._check(self._lib.vx_probe_gather_spread(self._ctx, int(frame_index), out))
+        return int(out[0]), int(out[1]), int(out[2])
 
     def device_info(self):
         name = C.create_string_buffer(256)

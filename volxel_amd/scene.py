@@ -60,6 +60,16 @@ def perspective(fovy, aspect, near, far) -> np.ndarray:
     return m
 
 
+def ortho(left, right, bottom, top, near, far) -> np.ndarray:
+    """gl-matrix mat4.ortho (OpenGL clip z in [-1,1]).  [build]: the reference camera is perspective
+    only (scene.ts:65-72); BASELINE config 1 asks for parallel rays."""
+    lr, bt, nf = 1.0 / (left - right), 1.0 / (bottom - top), 1.0 / (near - far)
+    m = np.zeros((4, 4), dtype=np.float64)
+    m[0, 0], m[1, 1], m[2, 2], m[3, 3] = -2.0 * lr, -2.0 * bt, 2.0 * nf, 1.0
+    m[0, 3], m[1, 3], m[2, 3] = (left + right) * lr, (top + bottom) * bt, (far + near) * nf
+    return m
+
+
 def scale_m(s) -> np.ndarray:
     m = mat4_identity()
     s = np.broadcast_to(np.asarray(s, dtype=np.float64), (3,))
@@ -81,11 +91,17 @@ class Camera:
     def __init__(self, distance: float = 1.0):
         self.view = np.zeros(3)                       # look-at point (scene.ts:11)
         self.pos = np.array([0.0, 0.0, -distance])    # scene.ts:12
+        # [build] None: the reference's perspective camera; a number: orthographic camera whose image
+        # spans +-ortho_half_height world units vertically (BASELINE config 1: 0.6)
+        self.ortho_half_height: float | None = None
 
     def view_matrix(self) -> np.ndarray:
         return look_at(self.pos, self.view, Camera.up)
 
     def proj_matrix(self, aspect: float, fov: float = math.pi / 3) -> np.ndarray:
+        if self.ortho_half_height is not None:
+            h = float(self.ortho_half_height)
+            return ortho(-h * aspect, h * aspect, -h, h, 0.1, 1000.0)
         return perspective(fov, aspect, 0.1, 1000.0)
 
 
