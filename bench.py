@@ -5,18 +5,27 @@
     python bench.py --gpus 1 --steps K --warmup W
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
 
-A "step" is one accumulation frame (one pass of the hot path over every pixel).  With N > 1
-the frame's 64x64 tiles are dealt round-robin to the ranks (volume replicated, no collective
-in the data path); the exchange step -- an RCCL all_gather of the per-rank slabs -- runs at
-display cadence, once per `--gather-every` accumulation frames (default 8), on a second HIP
-stream from a snapshot of the slab so that it overlaps the next frames.  Strong scaling: the
-frame is fixed, `value` = samples of all ranks / max-over-ranks time.
+A "step" is one accumulation frame: one pass of the hot path over every pixel, with the per-frame
+sub-pixel and start jitter of the reference (fragment.frag:146, raymarch.glsl:30) ON, so every frame
+marches its own rays.  With N > 1 the frame's 64x64 tiles are dealt to the ranks (volume replicated, no
+collective in the data path); the exchange step -- an RCCL all_gather of the per-rank slabs -- runs at
+display cadence, once per `--gather-every` accumulation frames, on a second HIP stream from a snapshot
+of the slab so that it overlaps the next frames.  Strong scaling: the frame is fixed, `value` = samples
+of all ranks / max-over-ranks time.
 
-Prints ONE JSON line on rank 0 (contract in the task statement), with
-  roofline     achieved algorithmic bytes (16 B/sample + 32 B/pixel) per launch /
-               average HIP-event kernel duration, against the 8 TB/s HBM peak;
-  cpu_baseline the scalar CPU oracle (oracle/, kind "port") timed on this box's host cores
-               (<= 16 threads) on the same frame.
+Prints ONE JSON line on rank 0 (contract in the task statement).  Besides the contract keys:
+  roofline      the dominant kernel (vx::render_dvr_cq<4>): ALGORITHMIC bytes of the launches actually
+                timed (16 B per sample, SURVEY 8(d), + 16 B per pixel per frame for the result the kernel
+                writes) / their mean HIP-event duration, against the 8 TB/s HBM peak; `traffic` = HBM bytes
+                per launch from the rocprofv3 PMC passes of this same command when profiles/traffic.json
+                holds them for exactly this launch shape, else null; `blend` = the merge kernel
+                (fragment.frag:158 applied in order), timed apart; `frames_per_launch_1` = the same
+                measurement with one frame per launch;
+  roofline.l1   the limiter the counters name (the vector L1 / texture path): gather instructions counted by
+                the kernel, distinct 128-byte lines per gather counted by a probe build of the same kernel,
+                clocks per gather per CU, and the floor the L1 sustains for that many line look-ups with no
+                arithmetic at all (vx_probe_gather_rate, measured in this run);
+  cpu_baseline  the scalar CPU oracle (oracle/, kind "port") timed on this box's host cores.
 """
 import argparse
 import json
@@ -31,7 +40,12 @@ sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0      # MI355X_MICROARCH.md: HBM3E peak 8.0 TB/s (spec)
 BYTES_PER_SAMPLE = 16.0    # 8 x 1 B voxels + 4 B range + 4 B indirection
-BYTES_PER_PIXEL = 32.0     # RGBA32F accumulator read + write
+BYTES_PER_PIXEL_RESULT = 16.0   # RGBA32F result written by the render kernel (one frame of one launch)
+BYTES_PER_PIXEL_BLEND = 32.0    # accumulator read + write by the blend (+32 B per pixel per frame
+                                # = this + nothing else when a frame is blended in the render kernel itself)
+DEFAULT_FRAMES_PER_LAUNCH = 16
+KERNEL = {None: "vx::render_dvr_cq<4>", 0: "vx::render_generic<3,0>", 1: "vx::render_dvr_cq<4>", 2: "vx::render_dvr_tile<8>"}
+LAYOUT = {None: "cellquad", 0: "reference", 1: "cellquad", 2: "brickf32"}
 
 
 def build_scene(width, height, n_vox, rank, world, device):
@@ -44,17 +58,23 @@ def build_scene(width, height, n_vox, rank, world, device):
     del vox
     r = Volxel3DRenderer(width, height, device=device, shard_rank=rank, shard_count=world)
     r.setup_from_grid(msg)
+    secs, nbytes, pinned = r.upload_stats()
     r.restore_settings(BENCHMARK_SETTINGS)      # TF stops, camera pose, histogram range, multiplier
     r.settings.render_mode = "dvr"
     r.settings.volume_clip_min = (0.25, 0.0, 0.0)
     r.settings.volume_clip_max = (1.0, 1.0, 0.75)
     r.settings.dvr_step_voxels = 0.5
     r.settings.dvr_ert_epsilon = 1e-4
+    r.settings.dvr_jitter = True        # distinct rays per accumulation frame, as the reference jitters
     r.settings.dvr_skip_empty = False   # BASELINE config 3 is ERT + clip box; skipping is reported aside
     r.settings.max_samples = 1 << 30
-    t3 = time.time()
     nb = int(np.prod(msg.indirection_size))
-    info = dict(gen_s=round(t1 - t0, 2), brick_build_s=round(t2 - t1, 2), upload_s=round(t3 - t2, 2),
+    info = dict(gen_s=round(t1 - t0, 2), brick_build_s=round(t2 - t1, 2),
+                upload={"seconds": round(secs, 4), "host_mb": round(nbytes / 1e6, 1),
+                        "host_gb_per_s": round(nbytes / secs / 1e9, 2) if secs > 0 else None,
+                        "pinned": bool(pinned),
+                        "note": "vx_upload_volume: PCIe copies from the caller's pinned pages + device-side "
+                                "layout build, overlapped; load-time cost, never inside `value`"},
                 bricks=nb, nonconstant_bricks=int(msg.brick_counter))
     return r, msg, info
 
@@ -65,7 +85,6 @@ def cpu_baseline(r, msg, crop=(1920, 1080)):
     from oracle import oracle as O
     p = r.bind_uniforms()
     W, H = r.width, r.height
-    x0, y0 = (W - crop[0]) // 2, (H - crop[1]) // 2
     tf, L = r._tf
     threads = min(os.cpu_count() or 1, 16)
     crop = (min(crop[0], W), min(crop[1], H))
@@ -89,28 +108,55 @@ def cpu_baseline(r, msg, crop=(1920, 1080)):
     except OSError:
         pass
     return {"value": round(c.samples / dt / 1e9, 5), "unit": "Gsamples/s", "cores": threads, "kind": "port",
-            "sample": f"centred {crop[0]}x{crop[1]} crop of the same frame, {c.samples} samples in {dt:.2f} s "
-                      f"({threads} threads over row bands)",
+            "sample": f"centred {crop[0]}x{crop[1]} crop of frame 0 of the same workload (jitter on), {c.samples} samples in "
+                      f"{dt:.2f} s ({threads} threads over row bands)",
             "ms_per_frame_crop": round(dt * 1e3, 1),
             "single_thread": {"value": round(c1.samples / dt1 / 1e9, 5), "unit": "Gsamples/s", "cores": 1,
                               "sample": f"centred {sw}x{sh} crop, {c1.samples} samples in {dt1:.2f} s"},
             "cpu_model": model, "host_cores": os.cpu_count()}
 
 
-def traffic_from_profile(a):
-    """HBM bytes per launch from the rocprofv3 PMC passes of this same command (collected by
-    tools/pmc_profile.sh, summarised into profiles/traffic.json): 2 x FETCH_SIZE (gfx950 reports
-    half of the fetched bytes, MI355X_MICROARCH.md section HBM) + WRITE_SIZE, in bytes."""
+def traffic_from_profile(a, frames_per_launch, jitter):
+    """HBM bytes per launch from the rocprofv3 PMC passes of this same command (tools/pmc_profile.sh ->
+    profiles/traffic.json): 2 x FETCH_SIZE (gfx950 reports half of the fetched bytes, MI355X_MICROARCH.md
+    section HBM) + WRITE_SIZE.  Only when the profiled launch shape is exactly the one timed here."""
     path = os.path.join(ROOT, "profiles", "traffic.json")
-    key = {None: "cellquad", 0: "reference", 1: "cellquad", 2: "brickf32"}[a.layout]
     try:
-        t = json.load(open(path))[key]
-        if (t["width"], t["height"], t["volume"], t.get("frames_per_launch", 32)) != \
-                (a.width, a.height, a.volume, max(1, min(64, a.frames_per_launch))):
-            return {"traffic": None}
-        return {"traffic": int(t["hbm_bytes_per_launch"]), "traffic_source": t["source"]}
+        for t in json.load(open(path)).get(LAYOUT[a.layout], []):
+            if (t["width"], t["height"], t["volume"], t["frames_per_launch"], bool(t["dvr_jitter"])) == \
+                    (a.width, a.height, a.volume, frames_per_launch, bool(jitter)):
+                return {"traffic": int(t["hbm_bytes_per_launch"]), "traffic_source": t["source"]}
     except Exception:
-        return {"traffic": None}
+        pass
+    return {"traffic": None}
+
+
+def l1_block(r, c, clock_khz_hint=None):
+    """the limiter the counters name: vector L1 / texture path.  Everything is measured in this run:
+    gathers (exact, by the kernel), their line spread (probe build of the same kernel on frame 0), the floor
+    (nothing-but-gathers kernel at the same number of line look-ups per instruction)."""
+    n, lines, quads = r.probe_gather_spread(0)
+    if not n or not c.gathers or not c.kernel_ms:
+        return None
+    name, cus, mem = r.device_info()
+    lpg, qpg = lines / n, quads / n
+    look = max(16, min(64, int(round(qpg))))
+    floor_clk, khz = r.probe_gather_rate(look)
+    ideal_clk, _ = r.probe_gather_rate(16)       # every group of 4 lanes inside one line: the best a gather can do
+    clk = (c.kernel_ms * 1e-3) * (khz * 1e3) * cus / c.gathers
+    return {"bound": "l1", "unit": "clk per gather instruction per CU at the nominal clock",
+            "nominal_clock_mhz": round(khz / 1e3, 1),
+            "gathers": int(c.gathers // max(c.launches, 1)),
+            "bytes_returned_per_gather": 1024,
+            "lines_per_gather": round(lpg, 2), "quad_lookups_per_gather": round(qpg, 2),
+            "clk_per_gather_per_cu": round(clk, 2), "floor_clk": round(floor_clk, 2),
+            "frac": round(floor_clk / clk, 4),
+            "floor_clk_if_coalesced": round(ideal_clk, 2), "frac_of_coalesced": round(ideal_clk / clk, 4),
+            "l1_return_gbs": round(c.gathers * 1024 / (c.kernel_ms * 1e-3) / 1e9, 1),
+            "note": "floor_clk = vx_probe_gather_rate(round(quad_lookups_per_gather)): global_load_dwordx4 only, "
+                    "L1-resident, same number of line look-ups per instruction; frac = floor / measured (<= 1, falls "
+                    "when the kernel adds stalls); frac_of_coalesced = what a march whose 4-lane groups never "
+                    "straddle a line would reach"}
 
 
 def main():
@@ -125,10 +171,14 @@ def main():
     ap.add_argument("--layout", type=int, default=None, help="0 reference, 1 cellquad (default), 2 brickf32 + LDS tiles")
     ap.add_argument("--gather-every", type=int, default=64,
                     help="N>1: all_gather the framebuffer once per this many accumulation frames")
-    ap.add_argument("--frames-per-launch", type=int, default=64,
+    ap.add_argument("--frames-per-launch", type=int, default=DEFAULT_FRAMES_PER_LAUNCH,
                     help="independent accumulation frames rendered by one kernel launch (1..64)")
+    ap.add_argument("--no-jitter", action="store_true",
+                    help="diagnostic: pixel-centre rays, identical in every frame (NOT the reference's behaviour)")
     ap.add_argument("--no-skip-variant", action="store_true", help="do not run the secondary measurement with skipping")
     ap.add_argument("--no-mode-variants", action="store_true", help="do not time the other render modes afterwards")
+    ap.add_argument("--no-side-measurements", action="store_true",
+                    help="skip the 1-frame-per-launch run and the L1 probes (profiling passes)")
     ap.add_argument("--force-gather", action="store_true", help="run the gather path with one rank too (testing)")
     ap.add_argument("--no-balance", action="store_true",
                     help="N>1: keep the default round-robin dealing of the 64x64 tiles instead of the cost-balanced order")
@@ -158,11 +208,13 @@ def main():
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local))
 
     r, msg, info = build_scene(a.width, a.height, a.volume, rank, world, local)
+    if a.no_jitter:
+        r.settings.dvr_jitter = False
     if a.layout is not None:
         r.set_layout(a.layout)
     r.bind_uniforms()
     if world > 1 and not a.no_balance:
-        # every rank probes the same 510 tile costs on its own GPU and derives the same dealing order:
+        # every rank probes the same tile costs on its own GPU and derives the same dealing order:
         # no communication, equal tile counts per rank, the gathered image stays bit-identical
         r.balance_tiles()
         r.bind_uniforms()
@@ -181,12 +233,12 @@ def main():
 
     P = max(1, min(64, a.frames_per_launch))
 
-    def batch(f0, n):
-        """n accumulation frames f0.. (n <= P): one launch, then -- at display cadence -- the gather"""
+    def batch(f0, n, per_launch):
+        """n accumulation frames f0.. (n <= per_launch): one launch, then -- at display cadence -- the gather"""
         if state["copy_done"] is not None:        # the snapshot copy must have read the slab
             rs.wait_event(state["copy_done"])
             state["copy_done"] = None
-        r.render(frames=n, rebind=False, in_flight=P)
+        r.render(frames=n, rebind=False, in_flight=per_launch)
         f = f0 + n - 1
         if use_dist and (f + 1) // a.gather_every != f0 // a.gather_every:
             gather()
@@ -216,12 +268,12 @@ def main():
         r.finish()
         torch.cuda.synchronize()
 
-    def run(first, count, need_image=False):
+    def run(first, count, need_image=False, per_launch=P):
         done, before = 0, state["gathers"]
-        while done < count:                   # equal launches: 80 frames at P = 64 go as 40 + 40
-            launches_left = -(-(count - done) // P)
+        while done < count:                   # equal launches: 20 frames at 16 per launch go as 10 + 10
+            launches_left = -(-(count - done) // per_launch)
             n = -(-(count - done) // launches_left)
-            batch(first + done, n)
+            batch(first + done, n, per_launch)
             done += n
         if need_image and use_dist and state["gathers"] == before:
             gather()                          # a timed run always delivers at least one gathered image
@@ -235,7 +287,7 @@ def main():
     elapsed = time.perf_counter() - t0
     c = r.counters()
 
-    samples, pixels, kernel_ms, slots = c.samples, c.pixels, c.kernel_ms, c.lane_slots
+    samples, pixels = c.samples, c.pixels
     if use_dist:
         t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -251,9 +303,29 @@ def main():
     if rank == 0:
         name, cus, mem = r.device_info()
         launches = max(c.launches, 1)
-        alg_bytes_launch = (c.samples * BYTES_PER_SAMPLE + c.pixels * BYTES_PER_PIXEL) / launches
+        multi = c.max_launch_frames > 1      # multi-frame launches write results; the blend kernel is apart
+        px_bytes = BYTES_PER_PIXEL_RESULT if multi else BYTES_PER_PIXEL_BLEND
+        alg_bytes_launch = (c.samples * BYTES_PER_SAMPLE + c.pixels * px_bytes) / launches
         avg_kernel_s = c.kernel_ms / launches / 1e3
         achieved = alg_bytes_launch / avg_kernel_s / 1e9 if avg_kernel_s > 0 else 0.0
+        fpl = int(c.max_launch_frames)
+        roof = {
+            "bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+            "frac": round(achieved / HBM_PEAK_GBS, 4),
+            **traffic_from_profile(a, fpl, r.settings.dvr_jitter),
+            "kernel": KERNEL[a.layout],
+            "avg_kernel_ms": round(c.kernel_ms / launches, 4), "launches": int(c.launches), "frames": int(c.frames),
+            "frames_per_launch": fpl, "min_frames_per_launch": int(c.min_launch_frames),
+            "algorithmic_bytes_per_launch": int(alg_bytes_launch),
+            "algorithmic_model": f"{int(BYTES_PER_SAMPLE)} B/sample + {int(px_bytes)} B/pixel/frame "
+                                 + ("(the result this kernel writes; the blend's 32 B/pixel/frame are in `blend`)"
+                                    if multi else "(accumulator read + write in the same kernel)"),
+            "rank0_gsamples_per_s_kernel_only": round(c.samples / (c.kernel_ms / 1e3) / 1e9, 3) if c.kernel_ms else None,
+            "blend": {"kernel": "vx::merge_results", "ms_per_launch": round(c.merge_ms / launches, 4),
+                      "algorithmic_bytes_per_launch": int(c.pixels / launches * (BYTES_PER_PIXEL_RESULT + BYTES_PER_PIXEL_BLEND / max(fpl, 1))),
+                      "note": "reads the per-frame results, applies fragment.frag:158 in frame order, one accumulator "
+                              "read + write per launch"} if multi else None,
+        }
         out = {
             "metric": "Gsamples/s raymarch @512^3 vol, 1080p; achieved HBM GB/s vs peak, 1/2/4/8 GPU",
             "value": round(samples / elapsed / 1e9, 3),
@@ -270,43 +342,56 @@ def main():
             "config": {
                 "workload": f"config3: {a.volume}^3 value-noise volume (seed 42), {a.width}x{a.height}, "
                             "DVR trilinear + 128-entry TF LUT (benchmark.json stops), step 0.5 voxel, "
-                            "ERT eps 1e-4, clip box (0.25,0,0)-(1,1,0.75)",
+                            "ERT eps 1e-4, clip box (0.25,0,0)-(1,1,0.75), per-frame sub-pixel + start jitter "
+                            + ("on" if r.settings.dvr_jitter else "OFF (diagnostic)"),
+                "dvr_jitter": bool(r.settings.dvr_jitter),
                 "parallelism": (f"image-tiles x{world} (64x64 tiles, "
                                 f"{'cost-balanced dealing order' if (world > 1 and not a.no_balance) else 'round-robin'}, volume replicated, RCCL "
                                 f"all_gather of the framebuffer every {a.gather_every} frames, overlapped)")
                                if use_dist else "1 GPU",
                 "gathers": state["gathers"],
-                "layout": {None: "cellquad", 0: "reference", 1: "cellquad", 2: "brickf32"}[a.layout],
+                "layout": LAYOUT[a.layout],
                 "samples_per_frame": int(samples // a.steps),
-                "frames_per_launch": P,
-                "lane_utilisation": round(c.samples / slots, 4) if slots else None,
+                "frames_per_launch": fpl, "frames_per_launch_requested": P,
+                "timed_region_s": round(elapsed, 4),
+                "lane_utilisation": round(c.samples / c.lane_slots, 4) if c.lane_slots else None,
                 "device": name, "cus": cus, **info,
             },
-            "roofline": {
-                "bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                "frac": round(achieved / HBM_PEAK_GBS, 4), **traffic_from_profile(a),
-                "kernel": {None: "vx::render_dvr_cq<4>", 0: "vx::render_generic<3,0>", 1: "vx::render_dvr_cq<4>", 2: "vx::render_dvr_tile<8>"}[a.layout],
-                "avg_kernel_ms": round(c.kernel_ms / launches, 4), "launches": int(c.launches), "frames": int(c.frames),
-                "algorithmic_bytes_per_launch": int(alg_bytes_launch),
-                "rank0_gsamples_per_s_kernel_only": round(c.samples / (c.kernel_ms / 1e3) / 1e9, 3) if c.kernel_ms else None,
-            },
+            "roofline": roof,
         }
+        if world == 1 and not a.no_side_measurements:
+            # (1) the same workload with ONE frame per launch (what a host that cannot batch frames gets)
+            r.reset_counters()
+            n1 = max(8, min(a.steps, 32))
+            run(max(a.warmup, 2) + a.steps, n1, per_launch=1)
+            r.finish()
+            c1 = r.counters()
+            alg1 = (c1.samples * BYTES_PER_SAMPLE + c1.pixels * BYTES_PER_PIXEL_BLEND) / max(c1.launches, 1)
+            k1 = c1.kernel_ms / max(c1.launches, 1) / 1e3
+            roof["frames_per_launch_1"] = {
+                "frames": int(c1.frames), "launches": int(c1.launches), "avg_kernel_ms": round(k1 * 1e3, 4),
+                "gsamples_per_s_kernel_only": round(c1.samples / (c1.kernel_ms / 1e3) / 1e9, 3),
+                "achieved": round(alg1 / k1 / 1e9, 1), "frac": round(alg1 / k1 / 1e9 / HBM_PEAK_GBS, 4),
+                "algorithmic_model": "16 B/sample + 32 B/pixel/frame (accumulator read + write in the same kernel)"}
+            # (2) the limiter the counters name
+            if a.layout in (None, 1):
+                roof["l1"] = l1_block(r, c)
         if world == 1 and not a.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(r, msg)
         else:
             out["cpu_baseline"] = None
         if world == 1 and not a.no_skip_variant:
-            # same frame with the exact empty-space skipping switched on (fewer samples are
+            # same frames with the exact empty-space skipping switched on (fewer samples are
             # evaluated, so the headline metric above is quoted without it)
             r.settings.dvr_skip_empty = True
             r.bind_uniforms()
             r.render(frames=5, rebind=False); r.finish(); r.reset_counters()
             r.render(frames=P, rebind=False, in_flight=P); r.finish()
-            cs = r.counters()
+            cs_ = r.counters()
             out["config"]["with_empty_space_skipping"] = {
-                "ms_per_frame": round(cs.kernel_ms / cs.frames, 4),
-                "samples_per_frame": int(cs.samples // cs.frames),
-                "gsamples_per_s": round(cs.samples / cs.kernel_ms / 1e6, 1)}
+                "ms_per_frame": round(cs_.kernel_ms / cs_.frames, 4),
+                "samples_per_frame": int(cs_.samples // cs_.frames),
+                "gsamples_per_s": round(cs_.samples / cs_.kernel_ms / 1e6, 1)}
             r.settings.dvr_skip_empty = False
         if world == 1 and not a.no_mode_variants:
             # the other render modes on the same scene (kernel ms per accumulation frame; not the metric)
@@ -317,9 +402,10 @@ def main():
                 r.bind_uniforms()
                 r.render(frames=3, rebind=False); r.finish(); r.reset_counters()
                 r.render(frames=P, rebind=False, in_flight=P); r.finish()
-                cs = r.counters()
-                other[mode] = {"ms_per_frame": round(cs.kernel_ms / cs.frames, 4),
-                               "samples_per_frame": int(cs.samples // cs.frames)}
+                cs_ = r.counters()
+                other[mode] = {"ms_per_frame": round(cs_.kernel_ms / cs_.frames, 4),
+                               "samples_per_frame": int(cs_.samples // cs_.frames),
+                               "frames_per_launch": int(cs_.max_launch_frames)}
             out["config"]["other_modes"] = other
         real_stdout.write(json.dumps(out) + "\n")
         real_stdout.flush()

@@ -74,6 +74,8 @@ void vxo_histogram_gradient(const uint32_t* hist, uint32_t n, int32_t* smoothed,
 
 /* ---- shader-side lookups (shaders/sampling/common.glsl) ---- */
 float vxo_lookup_density_brick(const VxoVolume* v, int32_t x, int32_t y, int32_t z);
+float vxo_trilinear_cell(const VxoVolume* v, float density_scale, int32_t ix, int32_t iy, int32_t iz,
+                         float fx, float fy, float fz);
 float vxo_lookup_density_trilinear(const VxoVolume* v, float density_scale, float px, float py,
                                    float pz);
 float vxo_lookup_majorant(const VxoVolume* v, float density_scale, float px, float py, float pz,

@@ -25,6 +25,11 @@ CASES = {
                          dict(clip_min=(0.25, 0, 0), clip_max=(1, 1, 0.75), bench=True)),
     "noise32_dvr_jitter_f3": ("noise", 32, (32, 32), "dvr", dict(dvr_jitter=True, frame=3, bench=True)),
     "noise32_phong": ("noise", 32, (32, 32), "dvr_phong", dict(bench=True)),
+    "noise32_phong_jitter_f2": ("noise", 32, (40, 32), "dvr_phong", dict(bench=True, dvr_jitter=True, frame=2,
+                                                                         clip_min=(0.25, 0, 0), clip_max=(1, 1, 0.75))),
+    # [build] orthographic camera (BASELINE config 1)
+    "sphere32_dvr_ortho": ("sphere", 32, (40, 32), "dvr", dict(ortho=0.6)),
+    "noise32_dvr_ortho_jitter_f1": ("noise", 32, (40, 32), "dvr", dict(bench=True, ortho=0.7, dvr_jitter=True, frame=1)),
     "noise32_raymarch": ("noise", 32, (32, 32), "raymarch", dict(bench=True, frame=2)),
     "noise32_no_dda": ("noise", 32, (32, 32), "no_dda", dict(bench=True, frame=1)),
     "noise32_default": ("noise", 32, (32, 32), "default", dict(bench=True, frame=4)),
@@ -151,7 +156,7 @@ def main():
     for name in CASES:
         img, c = render_case(O, name)
         np.savez_compressed(os.path.join(HERE, name + ".npz"), image=img, samples=np.uint64(c.samples),
-                            rays=np.uint64(c.rays))
+                            rays=np.uint64(c.rays), grad_samples=np.uint64(c.grad_samples))
         print(name, img.shape, "samples", c.samples, "max", float(img[..., :3].max()))
     np.savez_compressed(os.path.join(HERE, "env_default.npz"), **env_fixture(O))
     np.savez_compressed(os.path.join(HERE, "tf_tables.npz"), **tf_fixture())

@@ -54,7 +54,8 @@ def test_unorm_table():
 
 @pytest.mark.parametrize("layout", [0, 1, 2])
 @pytest.mark.parametrize("name", ["sphere32_debughits", "sphere32_dvr", "noise32_dvr_clip",
-                                  "noise32_dvr_jitter_f3", "noise32_phong"])
+                                  "noise32_dvr_jitter_f3", "noise32_phong", "noise32_phong_jitter_f2",
+                                  "sphere32_dvr_ortho", "noise32_dvr_ortho_jitter_f1"])
 def test_golden_deterministic(oracle, name, layout):
     from tests.golden.make_golden import build_case
     grid, tf, L, p, frame = build_case(oracle, name)
@@ -63,9 +64,15 @@ def test_golden_deterministic(oracle, name, layout):
     r.reset_counters()
     img = _render_with_params(r, p, frame)
     c = r.counters()
-    assert np.abs(img - want["image"]).max() <= 2e-6, name
+    # Phong: the kernels evaluate the Blinn terms on the hardware's 1-ulp rsq / log2 / exp2 (pow = exp2(n*log2 x),
+    # n = 32), the oracle on libm: 1e-5, still ten times inside the 1e-4 budget of BASELINE.md
+    tol = 1e-5 if "phong" in name else 2e-6
+    err = float(np.abs(img - want["image"]).max())
+    assert err <= tol, (name, err)
     assert c.samples == int(want["samples"]) and c.rays == int(want["rays"])
     assert c.pixels == p.res[0] * p.res[1]
+    if "phong" in name:
+        assert c.grad_samples == int(want["grad_samples"])
     if "debughits" in name:
         hit = want["image"][..., 3] == 1  # all pixels; ray-gen + slab are IEEE-exact:
         box = np.abs(want["image"][..., :3] - 0.01).max(axis=2) > 1e-9
@@ -213,6 +220,75 @@ def test_config1_sphere_256_live_oracle(oracle):
             c = r.counters()
             assert np.abs(img - want).max() <= 2e-6
             assert c.samples == oc.samples and c.rays == oc.rays
+
+
+def test_config1_sphere_256_ortho_live_oracle(oracle):
+    """BASELINE config 1 as written: 64^3 sphere, 256x256 ORTHO ([build] parallel rays, half height 0.6; the
+    reference camera is perspective only, scene.ts:65-72), default white ramp; DVR, jittered DVR and debugHits"""
+    from tests.common import make_scene
+    from volxel_amd import synth, default_transfer_function
+    vox, sp = synth.sphere(64)
+    g = oracle.BrickGrid(vox, sp)
+    tf, L = default_transfer_function()
+    for kw, frame in ((dict(), 0), (dict(debug_hits=True), 0), (dict(dvr_jitter=True), 3)):
+        s, cam, vol, ds, p = make_scene(g, 256, 256, "dvr", ortho=0.6, **kw)
+        assert p.camera_ortho == 1
+        want, oc = oracle.render(p, g, tf, L, frame_index=frame)
+        for layout in (0, 1, 2):
+            r = _renderer(g, tf, L, p, layout)
+            img = _render_with_params(r, p, frame=frame)
+            c = r.counters()
+            assert np.abs(img - want).max() <= 2e-6
+            assert c.samples == oc.samples and c.rays == oc.rays
+            r.close()
+    # the host class binds the same block (Camera.ortho_half_height)
+    from volxel_amd import Volxel3DRenderer
+    r = Volxel3DRenderer(256, 256)
+    r.setup_from_grid(g)
+    r.settings.render_mode = "dvr"
+    r.settings.dvr_jitter = True
+    r.camera.ortho_half_height = 0.6
+    pb = r.bind_uniforms()
+    assert pb.camera_ortho == 1 and pb.camera_proj[:] == p.camera_proj[:] and pb.camera_proj_inv[:] == p.camera_proj_inv[:]
+    assert pb.camera_view_inv[:] == p.camera_view_inv[:] and pb.dvr_jitter == 1
+    r.close()
+
+
+def test_device_rng_known_answers(oracle):
+    """rows A1/A2 on the device itself: TEA, Wang hash, the xoshiro128++ variant (s.x + s.z, quirk Q1) and the
+    u24 -> f32 conversion of random.glsl:41-106 read back word for word (vx_debug_rng), against the committed
+    known answers and against the oracle on further seeds"""
+    import json
+    from volxel_amd import Volxel3DRenderer
+    kat = json.load(open(os.path.join(GOLD, "rng_kat.json")))
+    r = Volxel3DRenderer(64, 64)
+    L = r._lib
+
+    def run(op, a, b, n):
+        a = np.ascontiguousarray(a, dtype=np.uint32)
+        b = np.ascontiguousarray(b if b is not None else a, dtype=np.uint32)
+        out = np.zeros(n, dtype=np.uint32)
+        r._check(L.vx_debug_rng(r._ctx, op, a.ctypes.data, b.ctypes.data, n, out.ctypes.data))
+        return out
+    tea = kat["tea"]
+    assert run(0, [e["v0"] for e in tea], [e["v1"] for e in tea], len(tea)).tolist() == [e["out"] for e in tea]
+    wang = kat["wang"]
+    assert run(1, [e["x"] for e in wang], None, len(wang)).tolist() == [e["out"] for e in wang]
+    for e in kat["xoshiro"]:
+        assert run(2, [e["seed"]], None, len(e["out"])).tolist() == e["out"]
+    # beyond the committed vectors: pixel seeds as fragment.frag:143 forms them, long streams, float bits
+    rng = np.random.default_rng(12)
+    v0 = (42 * rng.integers(0, 1920 * 1080, 512, dtype=np.uint64)).astype(np.uint32)
+    v1 = rng.integers(0, 2000, 512, dtype=np.uint32)
+    OL = oracle.lib()
+    want = [OL.vxo_tea(int(a), int(b), 32) for a, b in zip(v0, v1)]
+    assert run(0, v0, v1, 512).tolist() == want
+    for seed in (want[0], want[17], 0xffffffff):
+        raw, flt = oracle.rng_stream(seed, 300)
+        assert np.array_equal(run(2, [seed], None, 300), raw)
+        assert np.array_equal(run(3, [seed], None, 300), np.asarray(flt, dtype=np.float32).view(np.uint32))
+    assert L.vx_debug_rng(r._ctx, 7, v0.ctypes.data, v1.ctypes.data, 4, v0.ctypes.data) != 0   # bad op
+    r.close()
 
 
 def test_ct_phantom_clip_anisotropic_live_oracle(oracle):
@@ -557,6 +633,65 @@ def test_error_contract():
         r.change_transfer_func(np.zeros(7, dtype=np.float32), 2)
 
 
+def test_host_rejects_arrays_shorter_than_their_size_fields(oracle):
+    """the C ABI takes raw pointers: the binding checks lengths before the call"""
+    import copy
+    from volxel_amd import Volxel3DRenderer, VolxelError, synth
+    vox, sp = synth.sphere(32)
+    g = oracle.BrickGrid(vox, sp)
+    r = Volxel3DRenderer(64, 64)
+    for field in ("indirection", "range", "atlas"):
+        bad = copy.copy(g)
+        setattr(bad, field, np.asarray(getattr(g, field))[:-8])
+        with pytest.raises(VolxelError, match=field):
+            r.setup_from_grid(bad)
+    bad = copy.copy(g)
+    bad.range_mipmaps = [(np.asarray(m)[:-2], st) for m, st in g.range_mipmaps]
+    with pytest.raises(VolxelError, match="mipmap"):
+        r.setup_from_grid(bad)
+    r.setup_from_grid(g)          # the intact grid still loads
+    r.close()
+
+
+def test_counters_report_the_launches_that_ran(oracle):
+    """vx_get_counters: frames per launch as launched (not as requested), gather instructions of the tuned
+    kernel, the blend time apart from the render time"""
+    from tests.common import benchmark_tf
+    from volxel_amd import Volxel3DRenderer, synth
+    vox, sp = synth.value_noise(64, seed=2, zero_quantile=0.4)
+    g = oracle.BrickGrid(vox, sp)
+    r = Volxel3DRenderer(192, 128)
+    r.setup_from_grid(g)
+    r.change_transfer_func(*benchmark_tf())
+    r.settings.render_mode = "dvr"
+    r.settings.dvr_jitter = True
+    r.settings.dvr_skip_empty = False
+    r.render(frames=2); r.finish(); r.reset_counters()       # the first frames build the launch order one by one
+    r.render(frames=20, rebind=False, in_flight=64); r.finish()
+    c = r.counters()
+    assert (c.launches, c.frames, c.min_launch_frames, c.max_launch_frames) == (1, 20, 20, 20)
+    assert c.merge_ms > 0 and c.kernel_ms > 0
+    # 2 gathers per march step, issued in batches of 4 steps: between 2 per wave step and that plus one batch per wave
+    steps = c.lane_slots // 64
+    waves = 20 * (192 // 8) * (128 // 8)
+    assert 2 * steps <= c.gathers <= 2 * steps + 8 * waves + 8 * 20 * 4 * 16
+    r.reset_counters()
+    r.render(frames=7, rebind=False, in_flight=3); r.finish()
+    c = r.counters()
+    assert (c.launches, c.frames, c.min_launch_frames, c.max_launch_frames) == (3, 7, 1, 3)
+    # the spread probe marches the same rays: same gather count per frame, at least one line per quad of lanes
+    r.restart_rendering(); r.reset_counters(); r.render(); r.finish()
+    one = r.counters()
+    n, lines, quads = r.probe_gather_spread(0)
+    assert 2 * n == one.gathers
+    assert n <= lines <= 64 * n and lines <= quads <= 64 * n and 16 * n >= quads // 4
+    clk, khz = r.probe_gather_rate(16)
+    clk1, _ = r.probe_gather_rate(1)
+    clk64, _ = r.probe_gather_rate(64)
+    assert khz >= 1000000 and 10.0 < clk1 <= clk < clk64 < 400.0
+    r.close()
+
+
 # ---- full-size (BASELINE config 3: 512^3, 1080p) through size-independent properties --------
 @pytest.fixture(scope="module")
 def big_scene():
@@ -689,6 +824,111 @@ def test_balanced_tile_order_is_bit_identical_and_levels_the_shards(big_scene):
     assert c.samples + c.skip_steps == plain[-1]
     with pytest.raises(Exception, match="permutation"):
         keep.set_tile_order(np.zeros(510, dtype=np.uint32))
+
+
+# ---- BASELINE config 5: 1024^3 bricked volume, 3840x2160, 8 image-tile shards -----------------
+@pytest.fixture(scope="module")
+def huge_scene():
+    from volxel_amd import synth, read_u16_stack_to_grid, Volxel3DRenderer, BENCHMARK_SETTINGS
+    vox, sp = synth.value_noise(1024, seed=42)
+    msg = read_u16_stack_to_grid(vox, sp)
+    del vox
+    r = Volxel3DRenderer(3840, 2160)
+    r.setup_from_grid(msg)
+    r.restore_settings(BENCHMARK_SETTINGS)
+    r.settings.render_mode = "dvr"
+    r.settings.volume_clip_min = (0.25, 0.0, 0.0)
+    r.settings.volume_clip_max = (1.0, 1.0, 0.75)
+    r.settings.dvr_jitter = True
+    yield r, msg
+    r.close()
+
+
+def test_config5_1024_cubed_4k_eight_tile_shards(huge_scene):
+    """the 19.8 GB cellquad build, the 24-bit brick index arithmetic of the march, the 2040-tile dealing order and
+    the multi-frame launch at their full size (brick.rs:77-81 sets the limits): every one of the 8 shards, dealt
+    by the balanced order, reproduces its pixels of the unsharded 4K frame bit for bit; sample counts add up;
+    the tuned kernel equals the generic kernel on the reference layout"""
+    import torch
+    from volxel_amd import Volxel3DRenderer, tiles
+    from volxel_amd.dist import slab_tensor
+    r, msg = huge_scene
+    assert tuple(msg.indirection_size) == (128, 128, 128)
+    secs, nbytes, pinned = r.upload_stats()
+    assert nbytes >= msg.atlas.size and secs > 0
+    r.restart_rendering(); r.reset_counters()
+    r.render(frames=3, in_flight=1)              # frames 0..2, jittered: distinct rays per frame
+    base = r.read_accum(); c0 = r.counters()
+    assert np.isfinite(base).all() and base[..., 3].min() == 1.0
+    assert c0.pixels == 3 * 3840 * 2160 and c0.samples > 2e9
+    # multi-frame launch == frame by frame
+    r.restart_rendering(); r.reset_counters()
+    r.render(frames=3, in_flight=3)
+    assert np.array_equal(r.read_accum(), base) and r.counters().samples == c0.samples
+    # tuned cellquad kernel vs the generic kernel on the reference textures (every tap through range ->
+    # pointer -> atlas): same sample count, image within the exp tolerance
+    r.set_layout(0); r.restart_rendering(); r.reset_counters(); r.render(frames=3, in_flight=1)
+    ref = r.read_accum(); c1 = r.counters()
+    assert c1.samples == c0.samples and c1.rays == c0.rays
+    assert np.abs(ref - base).max() <= 2e-6
+    r.set_layout(1)
+    # 8 shards through ONE extra context (re-sharded in place; the volume is replicated per GPU in production)
+    N = 8
+    rr = Volxel3DRenderer(3840, 2160, shard_rank=0, shard_count=N)
+    rr.setup_from_grid(msg)
+    rr.settings = r.settings; rr.camera = r.camera; rr.env_strength = r.env_strength
+    rr.change_transfer_func(*r._tf)
+    perm = rr.balance_tiles()
+    assert sorted(perm.tolist()) == list(range(2040))
+    gathered = None
+    total, per_rank = 0, []
+    for rank in range(N):
+        rr.shard_rank = rank
+        rr.restart_rendering(); rr.reset_counters()
+        rr.render(frames=3, in_flight=3); rr.finish()
+        c = rr.counters()
+        total += c.samples
+        per_rank.append(c.samples + c.skip_steps)
+        sl = slab_tensor(rr)
+        if gathered is None:
+            gathered = torch.zeros(N * sl.numel(), dtype=torch.float32, device="cuda")
+        gathered[rank * sl.numel():(rank + 1) * sl.numel()] = sl
+    assert total == c0.samples
+    image = torch.empty(2160 * 3840 * 4, dtype=torch.float32, device="cuda")
+    torch.cuda.synchronize()
+    rr.detile(gathered.data_ptr(), image.data_ptr()); rr.finish()
+    assert np.array_equal(image.view(2160, 3840, 4).cpu().numpy(), base)
+    mean = sum(per_rank) / N
+    assert max(abs(x - mean) for x in per_rank) / mean < 0.03
+    rr.close()
+
+
+def test_volume_beyond_the_cellquad_index_range_is_refused(oracle):
+    """more than 2^32 quads (about 1550^3 voxels) cannot be indexed by the march's 32-bit quad offsets:
+    vx_upload_volume says so and names the layouts that work (vx_api.hip alloc_layout); brick.rs:77-81 allows
+    up to 1016 bricks per axis"""
+    from types import SimpleNamespace
+    from volxel_amd import Volxel3DRenderer, VolxelError
+    b = 200                                       # 200^3 all-constant bricks: (201^3) * 576 quads > 2^32
+    n = b ** 3
+    msg = SimpleNamespace(
+        indirection=np.zeros(n, dtype=np.uint32), indirection_size=(b, b, b),
+        range=np.zeros(2 * n, dtype=np.uint16), range_size=(b, b, b),
+        atlas=np.zeros(0, dtype=np.uint8), atlas_size=(b * 8, b * 8, 0),
+        range_mipmaps=[(np.zeros(2 * (b >> k) ** 3, dtype=np.uint16), (b >> k, b >> k, b >> k)) for k in (1, 2, 3)],
+        index_extent=(b * 8, b * 8, b * 8), min_maj=(0.0, 1.0),
+        transform=np.eye(4, dtype=np.float32).reshape(-1))
+    r = Volxel3DRenderer(64, 64)
+    with pytest.raises(VolxelError, match="too large for the cellquad layout"):
+        r.setup_from_grid(msg)
+    with pytest.raises(VolxelError, match="without a volume|no volume"):
+        r.render()
+    r.set_layout(0)                               # the reference textures have no such limit
+    r.setup_from_grid(msg)
+    r.settings.render_mode = "dvr"
+    r.render(); img = r.read_accum()
+    assert np.isfinite(img).all()
+    r.close()
 
 
 def test_context_lifecycle_releases_device_memory(oracle):

@@ -1,6 +1,9 @@
 #!/usr/bin/env python3
 """Summarise the rocprofv3 output of tools/pmc_profile.sh into one text file for profiles/.
-usage: tools/pmc_summary.py gpurun_out/prof/<tag> <kernel-substring> > profiles/<name>.txt"""
+usage: tools/pmc_summary.py gpurun_out/prof/<tag> <kernel-substring> [profiles/<name>.txt] > profiles/<name>.txt
+With the third argument the HBM traffic per launch (2 x FETCH_SIZE + WRITE_SIZE, the gfx950 rule of
+MI355X_MICROARCH.md section HBM) is also recorded in profiles/traffic.json for bench.py's roofline.traffic,
+keyed by the launch shape the traced bench line reports."""
 import csv
 import glob
 import json
@@ -10,13 +13,20 @@ from collections import defaultdict
 
 root, kern = sys.argv[1], sys.argv[2]
 print(f"# rocprofv3 summary for kernels matching '{kern}' under {root}")
+cmd = os.path.join(root, "command.txt")
+if os.path.exists(cmd):
+    print("# command: python3 " + open(cmd).read().strip())
+
+
 def newest(pattern):
     fs = glob.glob(pattern, recursive=True)
     return [max(fs, key=os.path.getmtime)] if fs else []
 
+
 for f in newest(os.path.join(root, "kt", "**", "*kernel_stats.csv")):
     print("\n## kernel-trace --stats (" + os.path.relpath(f, root) + ")")
     print(open(f).read().strip())
+timed_grid = None
 for f in newest(os.path.join(root, "kt", "**", "*kernel_trace.csv")):
     by = defaultdict(list)
     for row in csv.DictReader(open(f)):
@@ -26,42 +36,58 @@ for f in newest(os.path.join(root, "kt", "**", "*kernel_trace.csv")):
     print("\n## kernel trace of '" + kern + "' by launch size (threads in x): calls, mean ms, min, max")
     for g, v in sorted(by.items()):
         print(f"grid {g:10d}: {len(v):3d} calls, mean {sum(v)/len(v):8.4f} ms, min {min(v):8.4f}, max {max(v):8.4f}")
+line = None
 bj = os.path.join(root, "bench_kt.json")
 if os.path.exists(bj) and os.path.getsize(bj):
-    print("\n## bench.py line of the traced run\n" + open(bj).read().strip())
+    txt = open(bj).read().strip()
+    print("\n## bench.py line of the traced run\n" + txt)
+    try:
+        line = json.loads(txt.splitlines()[-1])
+    except Exception:
+        line = None
+# the launches bench.py timed have frames_per_launch x (blocks of one frame) x 256 threads
+fpl = line["roofline"]["frames_per_launch"] if line else None
 print("\n## PMC counters: per-dispatch mean over the timed dispatches of the kernel")
+means = {}
 for d in sorted(glob.glob(os.path.join(root, "*"))):
     name = os.path.basename(d)
     if name == "kt" or not os.path.isdir(d):
         continue
     acc = defaultdict(list)
+    gsel = 0
     for f in newest(os.path.join(d, "**", "*counter_collection.csv")):
         rows = [r for r in csv.DictReader(open(f)) if kern in r.get("Kernel_Name", "")]
-        # only the full-size launches (bench.py default: 64 frames per launch); the first frames of a run are
-        # launched one by one while the launch order is being built
-        gmax = max((int(r["Grid_Size"]) for r in rows), default=0)
+        grids = sorted({int(r["Grid_Size"]) for r in rows})
+        if not grids:
+            continue
+        # the single-frame launches (launch-order refresh, first frames) have the smallest grid; the timed
+        # launches cover frames_per_launch frames
+        gsel = grids[0] * fpl if (fpl and grids[0] * fpl in grids) else grids[-1]
         for row in rows:
-            if int(row["Grid_Size"]) == gmax:
+            if int(row["Grid_Size"]) == gsel:
                 acc[row["Counter_Name"]].append(float(row["Counter_Value"]))
     for k, v in sorted(acc.items()):
-        print(f"{name:6s} {k:40s} mean {sum(v)/len(v):18.1f}  (n={len(v)}, grid {gmax})")
+        means[k] = sum(v) / len(v)
+        print(f"{name:6s} {k:40s} mean {sum(v)/len(v):18.1f}  (n={len(v)}, grid {gsel})")
 
-# ---- HBM traffic per launch (gfx950 rule: 2 x FETCH_SIZE + WRITE_SIZE), for bench.py's roofline.traffic
-if len(sys.argv) > 3:
-    import re
-    vals = {}
-    for d in ("fetch", "write"):
-        acc = []
-        for f in newest(os.path.join(root, d, "**", "*counter_collection.csv")):
-            rows = [r for r in csv.DictReader(open(f)) if kern in r.get("Kernel_Name", "")
-                    and r["Counter_Name"] in ("FETCH_SIZE", "WRITE_SIZE")]
-            gmax = max((int(r["Grid_Size"]) for r in rows), default=0)
-            acc += [float(r["Counter_Value"]) for r in rows if int(r["Grid_Size"]) == gmax]
-        vals[d] = sum(acc) / len(acc) if acc else None
-    if vals.get("fetch") and vals.get("write"):
-        out = {"cellquad": {"width": 1920, "height": 1080, "volume": 512, "fetch_size_kb": vals["fetch"],
-                            "write_size_kb": vals["write"],
-                            "hbm_bytes_per_launch": int((2 * vals["fetch"] + vals["write"]) * 1024),
-                            "source": sys.argv[3], "frames_per_launch": int(sys.argv[4]) if len(sys.argv) > 4 else 64}}
-        json.dump(out, open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "profiles", "traffic.json"), "w"), indent=1)
-        print(f"\n## traffic.json: 2 x {vals['fetch']:.0f} KB + {vals['write']:.0f} KB per launch")
+if len(sys.argv) > 3 and line and "FETCH_SIZE" in means and "WRITE_SIZE" in means:
+    cfg = line["config"]
+    w, h = [int(x) for x in cfg["workload"].split(", ")[1].split("x")]
+    vol = int(cfg["workload"].split(": ")[1].split("^")[0])
+    entry = {"width": w, "height": h, "volume": vol, "frames_per_launch": fpl, "dvr_jitter": cfg["dvr_jitter"],
+             "fetch_size_kb": means["FETCH_SIZE"], "write_size_kb": means["WRITE_SIZE"],
+             "hbm_bytes_per_launch": int((2 * means["FETCH_SIZE"] + means["WRITE_SIZE"]) * 1024),
+             "source": sys.argv[3] + " (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in separate passes of the same command; "
+                                     "2 x FETCH_SIZE per the MI355X_MICROARCH.md HBM note)"}
+    path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "profiles", "traffic.json")
+    try:
+        db = json.load(open(path))
+        if not isinstance(db.get(cfg["layout"], []), list):
+            db = {}
+    except Exception:
+        db = {}
+    key = ("width", "height", "volume", "frames_per_launch", "dvr_jitter")
+    rows = [e for e in db.get(cfg["layout"], []) if any(e.get(k) != entry[k] for k in key)]
+    db[cfg["layout"]] = rows + [entry]
+    json.dump(db, open(path, "w"), indent=1)
+    print(f"\n## traffic.json: 2 x {means['FETCH_SIZE']:.0f} KB + {means['WRITE_SIZE']:.0f} KB per {fpl}-frame launch")

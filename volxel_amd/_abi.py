@@ -12,7 +12,8 @@ import re
 
 _ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 INCLUDE_DIR = os.path.join(_ROOT, "include")
-LIB_PATH = os.path.join(os.path.dirname(os.path.abspath(__file__)), "libvolxel_hip.so")
+# VOLXEL_HIP_LIB: another build of the same library (variant probes of tools/); default: the in-tree build
+LIB_PATH = os.environ.get("VOLXEL_HIP_LIB") or os.path.join(os.path.dirname(os.path.abspath(__file__)), "libvolxel_hip.so")
 
 _CTYPES = {
     "float": C.c_float, "double": C.c_double, "int32_t": C.c_int32, "uint32_t": C.c_uint32,

@@ -11,7 +11,7 @@
 
 #include "../../include/volxel_brick.h"
 #include "vx_dvr.hpp"
-#include "vx_dvr_tile.hpp"
+#include "vx_dvr_lds.hpp"
 #include "vx_kernels.hpp"
 
 using namespace vx;
@@ -501,6 +501,10 @@ static int alloc_layout(VxContext* c, uint32_t& n_layers) {
   n_layers = 0;
   if (c->layout == VX_LAYOUT_BRICKF32) {
     uint64_t n_vox = (uint64_t)c->dv.bc[0] * c->dv.bc[1] * c->dv.bc[2] * 512u;
+    // the staging loads index the layout in 16-byte units with 32 bits: 64 GiB, about 2500^3 voxels
+    if (n_vox / 4u > 0xffffffffull)
+      VX_FAIL(c, VX_ERR_INVALID, "volume too large for the brickf32 layout (%llu voxels): select VX_LAYOUT_REFERENCE "
+              "with vx_set_layout", (unsigned long long)n_vox);
     VX_HIP(c, hipMalloc(&c->bf_alloc, n_vox * sizeof(float)));
     c->dv.bf = (const float*)c->bf_alloc;
     n_layers = c->dv.bc[2];
@@ -902,8 +906,9 @@ static int prepare_render(VxContext* c, dim3& grid) {
 }
 
 static bool is_tuned(const VxContext* c) {
-  return c->params.render_mode == VX_MODE_DVR && c->layout != VX_LAYOUT_REFERENCE && c->dvr_variant != 0 &&
-         !c->params.debug_hits && c->tf_len <= TF_LDS_MAX;
+  const bool dvr = c->params.render_mode == VX_MODE_DVR && c->layout != VX_LAYOUT_REFERENCE;
+  const bool phong = c->params.render_mode == VX_MODE_DVR_PHONG && c->layout == VX_LAYOUT_BRICKF32;
+  return (dvr || phong) && c->dvr_variant != 0 && !c->params.debug_hits && c->tf_len <= TF_LDS_MAX;
 }
 
 // one render-kernel launch into `out` (accumulator or a pipeline result slab)
@@ -911,7 +916,12 @@ static hipError_t launch_render(VxContext* c, uint32_t frame_index, float weight
                                 DevCounters* dc, hipStream_t stream) {
   bool tuned = is_tuned(c);
   if (tuned && c->layout == VX_LAYOUT_BRICKF32) {
-    launch_dvr_tile(c->params, c->dv, c->tf, c->tf_len, out, frame_index, weight, c->tm, dc, stream);
+    MultiOut mo{};
+    mo.count = 1;
+    mo.out[0] = out;
+    mo.dc[0] = dc;
+    mo.frame[0] = frame_index;
+    launch_dvr_lds(c->params, c->dv, c->tf, c->tf_len, mo, weight, c->tm, stream, c->use_order ? c->order : nullptr);
   } else if (tuned) {
     launch_dvr_cq(c->params, c->dv, c->tf, c->tf_len, out, frame_index, weight, c->tm, dc, stream,
                   (c->use_order && !c->dp_active()) ? c->order : nullptr);
@@ -953,7 +963,7 @@ int vx_render_frame(VxContext* c, uint32_t frame_index, float sample_weight) {
   VX_HIP(c, hipEventRecord(ev.a, c->stream));
   hipError_t le = launch_render(c, frame_index, sample_weight, grid, c->slab, c->dc, c->stream);
   VX_HIP(c, hipEventRecord(ev.b, c->stream));
-  const bool ordered = is_tuned(c) && c->layout == VX_LAYOUT_CELLQUAD && c->use_order && !c->dp_active();
+  const bool ordered = is_tuned(c) && c->use_order && !(c->dp_active() && c->layout == VX_LAYOUT_CELLQUAD);
   if (!ordered) c->order_builds_left = 0;
   if (ordered && le == hipSuccess && c->order_builds_left > 0) {
     c->order_builds_left--;
@@ -1025,7 +1035,8 @@ int vx_render_frames(VxContext* c, uint32_t first_frame, uint32_t count, const f
   ev.launches = count - done;
   hipError_t le = hipSuccess;
   const bool tuned_cq = is_tuned(c) && c->layout == VX_LAYOUT_CELLQUAD && !c->dp_active();
-  if (tuned_cq || !is_tuned(c)) {
+  const bool tuned_lds = is_tuned(c) && c->layout == VX_LAYOUT_BRICKF32;
+  if (tuned_cq || tuned_lds || !is_tuned(c)) {
     // several frames per launch (see MultiOut): one kernel for up to in_flight frames, then the
     // ordered blend of their results (the tuned cellquad DVR kernel and every render_generic mode)
     const uint32_t nqm = (uint32_t)c->slab_quads;
@@ -1049,6 +1060,9 @@ int vx_render_frames(VxContext* c, uint32_t first_frame, uint32_t count, const f
       if (tuned_cq)
         launch_dvr_cq_multi(c->params, c->dv, c->tf, c->tf_len, mo, 0.0f, c->tm, c->stream,
                             c->use_order ? c->order : nullptr);
+      else if (tuned_lds)
+        launch_dvr_lds(c->params, c->dv, c->tf, c->tf_len, mo, 0.0f, c->tm, c->stream,
+                       c->use_order ? c->order : nullptr);
       else
         launch_generic_mode(c, mo, 0.0f, grid, c->stream);
       le = hipGetLastError();
@@ -1070,8 +1084,7 @@ int vx_render_frames(VxContext* c, uint32_t first_frame, uint32_t count, const f
     if (le != hipSuccess) VX_FAIL(c, VX_ERR_DEVICE, "render kernel launch: %s", hipGetErrorString(le));
     return VX_OK;
   }
-  // the LDS-tile DVR kernel (brickf32) and the depth-parallel experiment: rolling window of frames on
-  // separate streams
+  // the depth-parallel experiment: rolling window of frames on separate streams
   VX_HIP(c, hipEventRecord(ev.a, c->stream));
   // rolling window: frame f renders on slot f % in_flight as soon as that slot's previous result has
   // been blended; the blends happen on the main stream, in frame order

@@ -244,13 +244,9 @@ VXD float lookup_density_nearest(const DevVolume& v, int x, int y, int z) {
   return lookup_density_brick(v, x, y, z);
 }
 
-// A5: lookup_density_trilinear, common.glsl:61-69
+// the eight taps of cell (ix,iy,iz) mixed x -> y -> z with the fractions given (common.glsl:62-68)
 template <int LAYOUT>
-VXD float lookup_density_trilinear(const DevVolume& v, float density_scale, V3 p) {
-  float qx = p.x - 0.5f, qy = p.y - 0.5f, qz = p.z - 0.5f;
-  float flx = floorf(qx), fly = floorf(qy), flz = floorf(qz);
-  float fx = qx - flx, fy = qy - fly, fz = qz - flz;
-  int ix = f2i(flx), iy = f2i(fly), iz = f2i(flz);
+VXD float trilinear_cell(const DevVolume& v, float density_scale, int ix, int iy, int iz, float fx, float fy, float fz) {
   float v000, v100, v010, v110, v001, v101, v011, v111;
   if (LAYOUT == LAYOUT_CQ) {
     // cell (ix,iy,iz) lives in apron brick (i+1)>>3 at local (i+1)&7; both z slices of the
@@ -287,6 +283,15 @@ VXD float lookup_density_trilinear(const DevVolume& v, float density_scale, V3 p
   float hx0 = gl_mix(v001, v101, fx);
   float hx1 = gl_mix(v011, v111, fx);
   return density_scale * gl_mix(gl_mix(lx0, lx1, fy), gl_mix(hx0, hx1, fy), fz);
+}
+
+// A5: lookup_density_trilinear, common.glsl:61-69
+template <int LAYOUT>
+VXD float lookup_density_trilinear(const DevVolume& v, float density_scale, V3 p) {
+  float qx = p.x - 0.5f, qy = p.y - 0.5f, qz = p.z - 0.5f;
+  float flx = floorf(qx), fly = floorf(qy), flz = floorf(qz);
+  float fx = qx - flx, fy = qy - fly, fz = qz - flz;
+  return trilinear_cell<LAYOUT>(v, density_scale, f2i(flx), f2i(fly), f2i(flz), fx, fy, fz);
 }
 
 // lookup_majorant, common.glsl:50-53 (range texture level `mip`, .x = R = max)
@@ -489,6 +494,30 @@ VXD float4 sample_environment(const VxParams& p, const DevVolume& dv, float u0, 
   V3 t = env_texture(dv.env_tex, dv.env_w, dv.env_h, uvx, uvy);
   float pdf = wsel / dv.env_avg_w;  // wsel = texel (px,py) of level 0, env_avg_w = level 9
   return make_float4(p.env_strength * t.x, p.env_strength * t.y, p.env_strength * t.z, pdf * inv_4pi);
+}
+
+// [build] Blinn-Phong terms of VX_MODE_DVR_PHONG on the hardware transcendentals (v_rsq_f32, v_log_f32, v_exp_f32:
+// 1 ulp each) instead of the device library's correctly rounded sqrt / divide / powf, which cost ~200 instructions
+// per shaded sample -- more than the whole march step.  The oracle keeps libm; the images agree within the stated
+// tolerance (the terms only scale a colour increment, no decision depends on them).
+VXD float rsq_fast(float x) { return __builtin_amdgcn_rsqf(x); }
+VXD float pow_fast(float x, float y) {   // x >= 0
+  if (y == 0.0f) return 1.0f;
+  return __builtin_amdgcn_exp2f(y * __builtin_amdgcn_logf(x));   // x == 0: exp2(-inf) = 0 for y > 0
+}
+// rgb of a sample shaded by the density gradient g (world space): n = -g/|g|, ambient + diffuse + Blinn specular
+VXD void phong_shade(const VxParams& p, V3 g, V3 nl, V3 hv, float4& rgba) {
+  const float g2 = dot3(g, g);
+  if (g2 > 1e-12f) {
+    const V3 n = scale3(g, -rsq_fast(g2));
+    const float ndl = gl_max(0.0f, dot3(n, nl));
+    const float ndh = gl_max(0.0f, dot3(n, hv));
+    const float diff = fma_(p.phong_kd, ndl, p.phong_ka);
+    const float spec = p.phong_ks * pow_fast(ndh, p.phong_shininess);
+    rgba.x = fma_(rgba.x, diff, spec);
+    rgba.y = fma_(rgba.y, diff, spec);
+    rgba.z = fma_(rgba.z, diff, spec);
+  }
 }
 
 VXD float sanitize1(float x) { return (x != x || __builtin_isinf(x)) ? 0.0f : x; }

@@ -1,0 +1,361 @@
+// vx_dvr_lds.hpp -- DVR (VX_MODE_DVR) and DVR + central-difference gradient + Blinn-Phong (VX_MODE_DVR_PHONG,
+// BASELINE config 4) on the "brickf32" layout: 8^3 bricks of decoded fp32 voxels in HBM, the active window of
+// voxels staged per wave through LDS ("volume laid out in 8^3 bricks, per-workgroup LDS staging of the active
+// brick", BASELINE north star).
+//
+// Why LDS: the cellquad kernel (vx_dvr.hpp) is bound by the vector L1's tag pipe -- the 64 lanes of a gather touch
+// ~10 distinct 128-byte lines but the L1 works on groups of 4 lanes and spends ~30 look-ups on them (bench.py
+// roofline.l1).  Here a wave fetches every voxel of its window ONCE with row-coalesced 16-byte loads (8 load
+// instructions per window instead of 2 per march step) and then takes the eight taps of a sample -- and the 24
+// further taps of a gradient -- from LDS, which has no tags.
+//
+// One wave = one 8x8-pixel tile, as everywhere.  Per window:
+//   1. anchor: the window is DIMX x DIMY x DIMZ voxels; per axis it starts at the smallest cell any live lane
+//      samples next (largest, if the wave marches in the negative direction), x rounded down to a multiple of 4;
+//   2. stage: lane = one (y,z) row of the window: up to 4 aligned 16-byte loads from the brick rows it crosses,
+//      all issued back to back, then 4 ds_write_b128; rows and chunks outside the volume are zeros (A4);
+//   3. march: up to S steps; a lane takes a step while the cell of its next sample (and, for Phong, the cells one
+//      voxel either side) lies inside the window, otherwise it waits for the next window.  Lanes advance at their
+//      own pace -- every ray still evaluates exactly its own sample sequence, so densities, TF bins, sample counts
+//      and termination are bit-identical to Frame<>::dvr and to the oracle.
+// No barriers: the tile is private to the wave.
+#pragma once
+#include "vx_dvr.hpp"
+
+namespace vx {
+
+// Window geometry.  X voxels per row are staged as four aligned 16-byte chunks; a row occupies RS words of LDS and a
+// z slice SS words.  RS = 20 and SS = 28 (mod 32) spread the lanes of a read over the 32 banks: RS steps rows by
+// 20 banks (eight consecutive rows land on eight different 4-bank groups), SS steps slices by 28.  With the natural
+// strides (16, 160) rows two apart and ALL slices alias: profiles/r02_lds_v1 shows the LDS spending a third of the
+// kernel time in bank conflicts.
+template <bool PHONG>
+struct LdsTile {
+  static constexpr int X = 16;                   // four 16-byte chunks per row
+  static constexpr int Y = PHONG ? 10 : 9;
+  static constexpr int Z = PHONG ? 10 : 9;
+  static constexpr int RS = 20;                  // row stride in words
+#ifndef VX_LDS_SS_PAD
+#define VX_LDS_SS_PAD 0
+#endif
+  static constexpr int SS = (PHONG ? 220 : 188) + VX_LDS_SS_PAD;   // slice stride in words: >= Y * RS, = 28 mod 32, multiple of 4
+  static constexpr int ROWS = Y * Z;
+  static constexpr int FLOATS = SS * Z;          // 6768 B (DVR) / 8800 B (Phong) per wave
+  static constexpr int PASSES = (ROWS + 63) / 64;
+  static constexpr int LO_MARGIN = PHONG ? 1 : 0;   // cells below the sample's cell that must be resident
+  static constexpr int HI_MARGIN = PHONG ? 2 : 1;   // taps above it (x+1; x+2 for the gradient)
+  static_assert(SS >= Y * RS && SS % 4 == 0 && RS % 4 == 0 && RS >= X, "tile strides");
+};
+
+// ---- wave64 integer min / max with DPP (row scan + row broadcasts), result in every lane ----
+template <int CTRL, int ROW_MASK, int BANK_MASK>
+VXD int dpp_src(int identity, int v) {
+  return __builtin_amdgcn_update_dpp(identity, v, CTRL, ROW_MASK, BANK_MASK, false);
+}
+template <bool IS_MIN>
+VXD int wave_minmax(int v) {
+  constexpr int ID = IS_MIN ? 0x7fffffff : (int)0x80000000;
+  auto op = [](int a, int b) { return IS_MIN ? (a < b ? a : b) : (a > b ? a : b); };
+  v = op(v, dpp_src<0x111, 0xf, 0xf>(ID, v));  // row_shr:1
+  v = op(v, dpp_src<0x112, 0xf, 0xf>(ID, v));  // row_shr:2
+  v = op(v, dpp_src<0x114, 0xf, 0xf>(ID, v));  // row_shr:4
+  v = op(v, dpp_src<0x118, 0xf, 0xf>(ID, v));  // row_shr:8   -> lane 15 of each row = row result
+  v = op(v, dpp_src<0x142, 0xa, 0xf>(ID, v));  // row_bcast:15 into rows 1 and 3
+  v = op(v, dpp_src<0x143, 0xc, 0xf>(ID, v));  // row_bcast:31 into rows 2 and 3
+  return __builtin_amdgcn_readlane(v, 63);
+}
+
+// one trilinear mix of eight taps, common.glsl:62-68 (without the density scale)
+VXD float mix8(float v000, float v100, float v010, float v110, float v001, float v101, float v011, float v111,
+               float fx, float wx, float fy, float wy, float fz, float wz) {
+  float lx0 = fma_(v100, fx, v000 * wx);
+  float lx1 = fma_(v110, fx, v010 * wx);
+  float hx0 = fma_(v101, fx, v001 * wx);
+  float hx1 = fma_(v111, fx, v011 * wx);
+  float l = fma_(lx1, fy, lx0 * wy);
+  float h = fma_(hx1, fy, hx0 * wy);
+  return fma_(h, fz, l * wz);
+}
+
+template <int S, bool PHONG, bool SKIP>
+__global__ __launch_bounds__(256) void render_dvr_lds(const VxParams p, const DevVolume v,
+                                                       const float4* __restrict__ tf_global, uint32_t tf_len,
+                                                       const MultiOut mo, float weight, const TileMap tm,
+                                                       const uint32_t* __restrict__ order) {
+  using TL = LdsTile<PHONG>;
+  constexpr int DX = TL::X, DY = TL::Y, DZ = TL::Z, RS = TL::RS, SS = TL::SS;
+  extern __shared__ float4 lds_raw[];
+  float4* tf_lds = lds_raw;
+  uint32_t* mask_lds = reinterpret_cast<uint32_t*>(lds_raw + tf_len);
+  float* tile = reinterpret_cast<float*>(mask_lds + (SKIP ? ((v.skip_words + 3u) & ~3u) : 0u)) + (threadIdx.x >> 6) * TL::FLOATS;
+  for (uint32_t i = threadIdx.x; i < tf_len; i += blockDim.x) tf_lds[i] = tf_global[i];
+  if (SKIP)
+    for (uint32_t i = threadIdx.x; i < v.skip_words; i += blockDim.x) mask_lds[i] = v.skip_bits[i];
+  __syncthreads();
+  const uint32_t fslot = mo.count > 1 ? blockIdx.x % mo.count : 0u;
+  const uint32_t bslot = mo.count > 1 ? blockIdx.x / mo.count : blockIdx.x;
+  const uint32_t blk = order ? order[bslot] : bslot;
+  float4* __restrict__ slab = mo.out[fslot];
+  DevCounters* __restrict__ dc = mo.dc[fslot];
+  const uint32_t frame = mo.frame[fslot];
+  uint32_t lt, sub;
+  if (!block_to_tile(blk, tm, lt, sub)) return;
+  const uint32_t wt = sub * 4u + (threadIdx.x >> 6), lane = threadIdx.x & 63u;
+  int px, py;
+  uint32_t si;
+  const bool in_image = wave_pixel(tm, lt, wt, lane, px, py, si);
+
+  DvrRay r{};
+  if (in_image) r = dvr_setup(p, px, py, frame);
+  bool alive = in_image && r.hit;
+  const uint32_t n_rays = (uint32_t)__builtin_popcountll(__ballot(alive));
+  // a lane is live while its next sample lies before `far`; a lane that misses, leaves the image or terminates
+  // gets far = -inf, so liveness is recomputed from registers each step instead of being carried as a flag
+  float far = alive ? r.far : -__builtin_inff();
+
+  const float scale = p.volume_density_scale, inv_maj = p.volume_inv_maj, maj = p.volume_maj;
+  const float sr0 = p.sample_range[0], sr1 = p.sample_range[1];
+  const float lenf = (float)tf_len;
+  const int last = (int)tf_len - 1;
+  const float ert = p.dvr_ert_tau;
+  const float max_steps_f = (float)p.dvr_max_steps;
+  const uint32_t ex = v.extent[0], ey = v.extent[1], ez = v.extent[2];
+  const uint32_t bcx = v.bc[0], bcy = v.bc[1];
+  const float4* __restrict__ bf4 = reinterpret_cast<const float4*>(v.bf);   // 16-byte units: 64 GiB of layout in 32 bits
+  const uint32_t sh = 3u + v.skip_level, md0 = v.skip_dims[0], md1 = v.skip_dims[1];
+  const uint32_t cmaxx = ex + 7u, cmaxy = ey + 7u, cmaxz = ez + 7u;
+  // Phong terms (vx_modes.hpp Frame::dvr<true>)
+  V3 nl = v3(-p.light_dir[0], -p.light_dir[1], -p.light_dir[2]);
+  V3 hv = v3(0.f, 0.f, 0.f);
+  if (PHONG) hv = normalize3(sub3(nl, r.wdir));
+  const float gsx = p.density_transform_inv[0], gsy = p.density_transform_inv[5], gsz = p.density_transform_inv[10];
+
+  float Cx = 0.f, Cy = 0.f, Cz = 0.f, T = 1.0f, tau = 0.0f, kf = 0.0f;   // kf: per-lane step index
+  uint32_t n_samples = 0, n_slots = 0, n_skipped = 0, n_grads = 0, n_loads = 0, n_reads = 0;   // wave-uniform
+
+  // cell of the lane's next sample
+  float t = 0.f, qx = 0.f, qy = 0.f, qz = 0.f, flx = 0.f, fly = 0.f, flz = 0.f;
+  int cxi = 0, cyi = 0, czi = 0;
+  auto next_sample = [&]() {
+    t = fma_(kf, r.dt, r.t0);
+    alive = (t < far) & (kf < max_steps_f);
+    qx = fma_(t, r.idir.x, r.ipos.x) - 0.5f;
+    qy = fma_(t, r.idir.y, r.ipos.y) - 0.5f;
+    qz = fma_(t, r.idir.z, r.ipos.z) - 0.5f;
+    flx = floorf(qx); fly = floorf(qy); flz = floorf(qz);
+    cxi = (int)flx; cyi = (int)fly; czi = (int)flz;
+  };
+  next_sample();
+
+  while (true) {
+    const unsigned long long live = __ballot(alive);
+    if (live == 0ull) break;
+    // ---- 1. anchor the window --------------------------------------------------------------------------
+    // the wave marches in the direction of its first live lane (rays of a wave are nearly parallel; any choice is
+    // correct, it only decides which end of the cell range the window hugs)
+    const int first = (int)__builtin_ctzll(live);
+    const bool fwx = __builtin_amdgcn_readlane(__builtin_bit_cast(int, r.idir.x), first) >= 0;   // sign bit clear
+    const bool fwy = __builtin_amdgcn_readlane(__builtin_bit_cast(int, r.idir.y), first) >= 0;
+    const bool fwz = __builtin_amdgcn_readlane(__builtin_bit_cast(int, r.idir.z), first) >= 0;
+    int LOx, LOy, LOz;
+    {
+      int mnx = wave_minmax<true>(alive ? cxi : 0x7fffffff), mxx = wave_minmax<false>(alive ? cxi : (int)0x80000000);
+      int mny = wave_minmax<true>(alive ? cyi : 0x7fffffff), mxy = wave_minmax<false>(alive ? cyi : (int)0x80000000);
+      int mnz = wave_minmax<true>(alive ? czi : 0x7fffffff), mxz = wave_minmax<false>(alive ? czi : (int)0x80000000);
+      // forward: start at the smallest cell; backward: end at the largest.  When the live cells fit the window
+      // with room to spare, centre the slack on the far side of the march (the side the rays move into).
+      LOx = fwx ? mnx - TL::LO_MARGIN : mxx + TL::HI_MARGIN - (DX - 1);
+      LOy = fwy ? mny - TL::LO_MARGIN : mxy + TL::HI_MARGIN - (DY - 1);
+      LOz = fwz ? mnz - TL::LO_MARGIN : mxz + TL::HI_MARGIN - (DZ - 1);
+      // x is staged in aligned 16-byte chunks: a forward window starts at or below its anchor cell (round down), a
+      // backward window ends at or above it (round up) -- the anchor stays inside, up to 3 columns are unused
+      LOx = fwx ? (LOx & ~3) : ((LOx + 3) & ~3);
+    }
+    // a lane can step while its sample's cell, with the margins, is inside [LO, LO + D)
+    auto inside = [&](int cx, int cy, int cz) {
+      uint32_t rx = (uint32_t)(cx - LOx - TL::LO_MARGIN), ry = (uint32_t)(cy - LOy - TL::LO_MARGIN),
+               rz = (uint32_t)(cz - LOz - TL::LO_MARGIN);
+      return (rx < (uint32_t)(DX - TL::LO_MARGIN - TL::HI_MARGIN)) & (ry < (uint32_t)(DY - TL::LO_MARGIN - TL::HI_MARGIN)) &
+             (rz < (uint32_t)(DZ - TL::LO_MARGIN - TL::HI_MARGIN));
+    };
+    if (__ballot(alive & inside(cxi, cyi, czi)) == 0ull) {
+      // lanes too far apart for one window (a wave astride two entry faces of the clip box): serve the first lane
+      LOx = __builtin_amdgcn_readlane(cxi, first) - TL::LO_MARGIN - (fwx ? 0 : DX - 1 - TL::LO_MARGIN - TL::HI_MARGIN);
+      LOx = fwx ? (LOx & ~3) : ((LOx + 3) & ~3);
+      LOy = __builtin_amdgcn_readlane(cyi, first) - TL::LO_MARGIN - (fwy ? 0 : DY - 1 - TL::LO_MARGIN - TL::HI_MARGIN);
+      LOz = __builtin_amdgcn_readlane(czi, first) - TL::LO_MARGIN - (fwz ? 0 : DZ - 1 - TL::LO_MARGIN - TL::HI_MARGIN);
+    }
+
+    // ---- 2. stage the window: lane = (y,z) row, four aligned 16-byte chunks --------------------------------
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");   // earlier tile reads are done
+    __builtin_amdgcn_wave_barrier();
+    {
+      // chunk c covers x = LOx + 4c .. +3: brick column and offset inside the brick row are wave uniform
+      uint32_t xoff[4];
+      bool xin[4];
+#pragma unroll
+      for (int c = 0; c < 4; ++c) {
+        const int gx = LOx + 4 * c;
+        xin[c] = (uint32_t)gx < ex;
+        xoff[c] = (((uint32_t)gx >> 3) << 7) + (((uint32_t)gx & 7u) >> 2);   // brick x * 128 + half row (16-byte units)
+      }
+      float4 vals[TL::PASSES][4];
+#pragma unroll
+      for (int ps = 0; ps < TL::PASSES; ++ps) {
+        const uint32_t row = lane + 64u * (uint32_t)ps;
+        const uint32_t zz = row / (uint32_t)DY, yy = row - zz * (uint32_t)DY;
+        const int gy = LOy + (int)yy, gz = LOz + (int)zz;
+        const bool rin = row < (uint32_t)TL::ROWS && (uint32_t)gy < ey && (uint32_t)gz < ez;
+        // 16-byte units from the start of the layout to the brick row (y,z) of brick column 0
+        const uint32_t rowbase = ((((uint32_t)gz >> 3) * bcy + ((uint32_t)gy >> 3)) * bcx << 7) +
+                                 ((((uint32_t)gz & 7u) << 4) | (((uint32_t)gy & 7u) << 1));
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+          float4 val = make_float4(0.f, 0.f, 0.f, 0.f);
+#ifndef VX_LDS_EXP_NOLOAD   // timing experiment only: no global loads
+          if (rin && xin[c]) val = bf4[rowbase + xoff[c]];
+#else
+          if (rin && xin[c]) val.x = (float)(rowbase + xoff[c]);
+#endif
+          vals[ps][c] = val;
+        }
+      }
+#pragma unroll
+      for (int ps = 0; ps < TL::PASSES; ++ps) {
+        const uint32_t row = lane + 64u * (uint32_t)ps;
+        if (row < (uint32_t)TL::ROWS) {
+          const uint32_t zz = row / (uint32_t)DY, yy = row - zz * (uint32_t)DY;
+          float4* dst = reinterpret_cast<float4*>(tile + zz * (uint32_t)SS + yy * (uint32_t)RS);
+#pragma unroll
+          for (int c = 0; c < 4; ++c) dst[c] = vals[ps][c];
+        }
+      }
+      n_loads += 4u * (uint32_t)TL::PASSES;
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+
+    // ---- 3. march: up to S steps out of LDS -------------------------------------------------------------------
+#pragma unroll 1
+    for (int s = 0; s < S; ++s) {
+      const bool go = alive & inside(cxi, cyi, czi);
+      const unsigned long long gm = __ballot(go);
+      if (gm == 0ull) break;                      // nobody can step in this window any more: restage
+      bool eval = go;
+      if (SKIP) {
+        uint32_t cx = (uint32_t)(cxi + 1), cy = (uint32_t)(cyi + 1), cz = (uint32_t)(czi + 1);
+        cx = cx < cmaxx ? cx : cmaxx; cy = cy < cmaxy ? cy : cmaxy; cz = cz < cmaxz ? cz : cmaxz;
+        uint32_t mi = ((cz >> sh) * md1 + (cy >> sh)) * md0 + (cx >> sh);
+        bool empty = (mask_lds[mi >> 5] >> (mi & 31u)) & 1u;
+        eval = go & !empty;
+        n_skipped += (uint32_t)__builtin_popcountll(__ballot(go & empty));
+      }
+      {
+        unsigned long long m = __ballot(eval);
+        n_samples += (uint32_t)__builtin_popcountll(m);
+        n_slots += 64u;
+      }
+      // word offset of the sample's cell in the tile; lanes that do not step read cell 0 (defined data)
+      // go: all three differences are in [0, 16): 24-bit multiplies (full rate) instead of v_mul_lo_u32
+      int off = (int)mad24((uint32_t)(czi - LOz), (uint32_t)SS, mad24((uint32_t)(cyi - LOy), (uint32_t)RS, (uint32_t)(cxi - LOx)));
+      off = go ? off : (TL::LO_MARGIN * (SS + RS + 1));
+      const float* tp = tile + off;
+      const float* tq = tp + SS;                  // slice z + 1
+#ifdef VX_LDS_EXP_NOREAD   // timing experiment only: one tap read instead of four
+      const float v000 = tp[0], v100 = tp[1], v010 = v000 * 0.5f, v110 = v100 * 0.5f;
+      const float v001 = v000 * 0.25f, v101 = v100 * 0.25f, v011 = v000 * 0.75f, v111 = v100 * 0.75f;
+      (void)tq;
+#else
+      const float v000 = tp[0], v100 = tp[1], v010 = tp[RS], v110 = tp[RS + 1];
+      const float v001 = tq[0], v101 = tq[1], v011 = tq[RS], v111 = tq[RS + 1];
+#endif
+      n_reads += 4u;
+      const float fx = qx - flx, fy = qy - fly, fz = qz - flz;
+      const float wx = 1.0f - fx, wy = 1.0f - fy, wz = 1.0f - fz;
+      // common.glsl:62-68: x lerps of the four rows, y lerps of the two slices, z lerp
+      const float lx0 = fma_(v100, fx, v000 * wx), lx1 = fma_(v110, fx, v010 * wx);
+      const float hx0 = fma_(v101, fx, v001 * wx), hx1 = fma_(v111, fx, v011 * wx);
+      const float ml = fma_(lx1, fy, lx0 * wy), mh = fma_(hx1, fy, hx0 * wy);
+      const float d = scale * fma_(mh, fz, ml * wz);
+      const float dn = d * inv_maj;
+      const int ti = med3_i32((int)(dn * lenf), 0, last);   // dn >= 0: truncation == floor
+      const bool in_range = !(dn < sr0 || dn > sr1);
+      float4 rgba = tf_lds[ti];
+      const float alpha = (eval && in_range) ? rgba.w : 0.0f;
+      const bool contrib = alpha > 0.0f;
+      if (PHONG) {
+        const unsigned long long cm = __ballot(contrib);
+        if (cm != 0ull) {   // wave-uniform: the 24 further taps only when some lane shades
+          n_grads += (uint32_t)__builtin_popcountll(cm);
+          n_reads += 12u;
+          if (contrib) {
+            // central differences one voxel either side, in the sample's cell frame (cells c +- e, the sample's
+            // fractions): T(c + e) - T(c - e) per axis, each T a full common.glsl:62-68 mix times the density scale
+            // x: T(c + ex) mixes the taps x+1, x+2 and T(c - ex) the taps x-1, x of the same four rows -- no lerp is shared
+            const float xm0 = tp[-1], xp0 = tp[2], xm1 = tp[RS - 1], xp1 = tp[RS + 2];
+            const float xm2 = tq[-1], xp2 = tq[2], xm3 = tq[RS - 1], xp3 = tq[RS + 2];
+            const float gx = scale * mix8(v100, xp0, v110, xp1, v101, xp2, v111, xp3, fx, wx, fy, wy, fz, wz) -
+                             scale * mix8(xm0, v000, xm1, v010, xm2, v001, xm3, v011, fx, wx, fy, wy, fz, wz);
+            // y: T(c + ey) mixes rows y+1, y+2 -- the x lerp of row y+1 is the centre's lx1 / hx1 (same operands, same
+            // operation: same bits); likewise T(c - ey) reuses lx0 / hx0
+            const float ym0 = tp[-RS], ym1 = tp[-RS + 1], yp0 = tp[2 * RS], yp1 = tp[2 * RS + 1];
+            const float ym2 = tq[-RS], ym3 = tq[-RS + 1], yp2 = tq[2 * RS], yp3 = tq[2 * RS + 1];
+            const float lxp = fma_(yp1, fx, yp0 * wx), hxp = fma_(yp3, fx, yp2 * wx);
+            const float lxm = fma_(ym1, fx, ym0 * wx), hxm = fma_(ym3, fx, ym2 * wx);
+            const float gy = scale * fma_(fma_(hxp, fy, hx1 * wy), fz, fma_(lxp, fy, lx1 * wy) * wz) -
+                             scale * fma_(fma_(hx0, fy, hxm * wy), fz, fma_(lx0, fy, lxm * wy) * wz);
+            // z: T(c + ez) mixes slices z+1, z+2 -- the y lerp of slice z+1 is the centre's mh; T(c - ez) reuses ml
+            const float* tzm = tp - SS;
+            const float* tzp = tq + SS;
+            const float zm0 = tzm[0], zm1 = tzm[1], zm2 = tzm[RS], zm3 = tzm[RS + 1];
+            const float zp0 = tzp[0], zp1 = tzp[1], zp2 = tzp[RS], zp3 = tzp[RS + 1];
+            const float mp = fma_(fma_(zp3, fx, zp2 * wx), fy, fma_(zp1, fx, zp0 * wx) * wy);
+            const float mm = fma_(fma_(zm3, fx, zm2 * wx), fy, fma_(zm1, fx, zm0 * wx) * wy);
+            const float gz = scale * fma_(mp, fz, mh * wz) - scale * fma_(ml, fz, mm * wz);
+            const V3 g = v3(gx * gsx, gy * gsy, gz * gsz);
+            phong_shade(p, g, nl, hv, rgba);
+          }
+        }
+      }
+      // tau += a*maj*dt; C += (T_prev - T) * rgb   (raymarch.glsl:43 / SURVEY A12) -- straight line, as vx_dvr.hpp
+      tau = fma_(alpha * maj, r.dt, tau);
+      const float Tn = __builtin_amdgcn_exp2f(tau * -1.4426950408889634f);
+      const float dT = contrib ? T - Tn : 0.0f;
+      Cx = fma_(dT, rgba.x, Cx);
+      Cy = fma_(dT, rgba.y, Cy);
+      Cz = fma_(dT, rgba.z, Cz);
+      const bool done = contrib && (tau >= ert);
+      T = contrib ? (done ? 0.0f : Tn) : T;
+      far = done ? -__builtin_inff() : far;
+      // the lanes that stepped move on to their next sample
+      kf = go ? kf + 1.0f : kf;
+      next_sample();
+    }
+  }
+
+  if (in_image) dvr_store(p, v, r, Cx, Cy, Cz, T, weight, slab, si);
+  const uint32_t n_px = (uint32_t)__builtin_popcountll(__ballot(in_image));
+  add_counts(dc, n_samples, n_rays, n_px, n_skipped, n_grads, n_slots, blk, n_loads, n_reads);
+}
+
+inline void launch_dvr_lds(const VxParams& p, const DevVolume& v, const float4* tf, uint32_t tf_len, const MultiOut& mo,
+                           float weight, const TileMap& tm, hipStream_t stream, const uint32_t* order) {
+  const uint32_t groups = (tm.tiles_per_shard + 7u) / 8u;
+  const dim3 grid(groups * 128u * (mo.count ? mo.count : 1u)), block(256);
+  const bool skip = p.dvr_skip_empty && v.skip_bits;
+  const bool phong = p.render_mode == VX_MODE_DVR_PHONG;
+  const size_t tile_bytes = 4u * (size_t)(phong ? LdsTile<true>::FLOATS : LdsTile<false>::FLOATS) * sizeof(float);
+  const size_t lds = (size_t)tf_len * sizeof(float4) + (skip ? (((size_t)v.skip_words + 3u) & ~(size_t)3u) * 4u : 0u) + tile_bytes;
+  constexpr int S = 16;
+#define VX_LAUNCH_LDS(PH, SK) \
+  hipLaunchKernelGGL((render_dvr_lds<S, PH, SK>), grid, block, lds, stream, p, v, tf, tf_len, mo, weight, tm, order)
+  if (phong) {
+    if (skip) VX_LAUNCH_LDS(true, true); else VX_LAUNCH_LDS(true, false);
+  } else {
+    if (skip) VX_LAUNCH_LDS(false, true); else VX_LAUNCH_LDS(false, false);
+  }
+#undef VX_LAUNCH_LDS
+}
+
+}  // namespace vx

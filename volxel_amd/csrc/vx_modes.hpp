@@ -335,22 +335,19 @@ struct Frame {
         if (rgba.w > 0.0f) {
           if (PHONG) {
             c.grads++;
-            float gx = trilinear(v3(ip.x + 1.0f, ip.y, ip.z)) - trilinear(v3(ip.x - 1.0f, ip.y, ip.z));
-            float gy = trilinear(v3(ip.x, ip.y + 1.0f, ip.z)) - trilinear(v3(ip.x, ip.y - 1.0f, ip.z));
-            float gz = trilinear(v3(ip.x, ip.y, ip.z + 1.0f)) - trilinear(v3(ip.x, ip.y, ip.z - 1.0f));
+            // [build] central differences one voxel either side, in the sample's own cell frame (cells c +- e, the
+            // sample's fractions): DESIGN.md section 2
+            float qx = ip.x - 0.5f, qy = ip.y - 0.5f, qz = ip.z - 0.5f;
+            float flx = floorf(qx), fly = floorf(qy), flz = floorf(qz);
+            float fx = qx - flx, fy = qy - fly, fz = qz - flz;
+            int cx = f2i(flx), cy = f2i(fly), cz = f2i(flz);
+            const float ds = p.volume_density_scale;
+            float gx = trilinear_cell<LAYOUT>(v, ds, cx + 1, cy, cz, fx, fy, fz) - trilinear_cell<LAYOUT>(v, ds, cx - 1, cy, cz, fx, fy, fz);
+            float gy = trilinear_cell<LAYOUT>(v, ds, cx, cy + 1, cz, fx, fy, fz) - trilinear_cell<LAYOUT>(v, ds, cx, cy - 1, cz, fx, fy, fz);
+            float gz = trilinear_cell<LAYOUT>(v, ds, cx, cy, cz + 1, fx, fy, fz) - trilinear_cell<LAYOUT>(v, ds, cx, cy, cz - 1, fx, fy, fz);
             V3 g = v3(gx * p.density_transform_inv[0], gy * p.density_transform_inv[5],
                       gz * p.density_transform_inv[10]);
-            float g2 = dot3(g, g);
-            if (g2 > 1e-12f) {
-              V3 n = scale3(g, -1.0f / sqrtf(g2));
-              float ndl = gl_max(0.0f, dot3(n, nl));
-              float ndh = gl_max(0.0f, dot3(n, hv));
-              float diff = fma_(p.phong_kd, ndl, p.phong_ka);
-              float spec = p.phong_ks * powf(ndh, p.phong_shininess);
-              rgba.x = fma_(rgba.x, diff, spec);
-              rgba.y = fma_(rgba.y, diff, spec);
-              rgba.z = fma_(rgba.z, diff, spec);
-            }
+            phong_shade(p, g, nl, hv, rgba);
           }
           tau = fma_(rgba.w * p.volume_maj, dt, tau);
           float Tn = expf(-tau);
