@@ -120,6 +120,40 @@ def test_golden_stochastic_modes(oracle, name, layout):
 
 
 # ---- row N3: environment-map lighting (environment.ts, envSetup.frag, environment.glsl) ----------
+@pytest.mark.parametrize("mode,bounces", [("default", 1), ("default", 3), ("no_dda", 2), ("raymarch", 1)])
+def test_repacked_path_kernel_is_bit_identical(oracle, mode, bounces, monkeypatch):
+    """vx_paths.hpp (VX_PATHS_KERNEL=packed): the collided paths of a 16x16-pixel workgroup are re-packed through LDS
+    between the primary and the shadow segments.  A path record carries its pixel's xoshiro state, so every pixel
+    draws exactly the stream of fragment.frag:79-124 whichever lane runs it: same image bits, same sample counts as
+    the one-pixel-per-lane kernel, on every layout, with and without the environment map, several frames per launch."""
+    from tests.common import make_scene, benchmark_tf, BENCH_CAM, small_noise
+    from volxel_amd import Volxel3DRenderer
+    vox, sp = small_noise(64, seed=9)
+    g = oracle.BrickGrid(vox, sp)
+    tf, L = benchmark_tf()
+    res = {}
+    for kern in ("generic", "packed"):
+        monkeypatch.setenv("VX_PATHS_KERNEL", kern)
+        for layout in (0, 1, 2):
+            r = Volxel3DRenderer(200, 136, layout=layout)       # not a multiple of 16: partial workgroups
+            r.setup_from_grid(g)
+            r.change_transfer_func(tf, L)
+            r.settings.render_mode, r.settings.bounces = mode, bounces
+            r.settings.sample_range = (0.05, 1.0)
+            r.settings.use_env = layout != 1                     # directional light on one layout, the map on the others
+            r.camera.pos = np.asarray(BENCH_CAM["cam_pos"], dtype=np.float64)
+            r.camera.view = np.asarray(BENCH_CAM["look_at"], dtype=np.float64)
+            r.reset_counters()
+            r.render(frames=7, in_flight=3)                      # frames 0..6: launches of 1, 1, 3 and 2 frames
+            c = r.counters()
+            res[(kern, layout)] = (r.read_accum(), c.samples, c.skip_steps, c.rays)
+            r.close()
+    for layout in (0, 1, 2):
+        a, b = res[("generic", layout)], res[("packed", layout)]
+        assert np.array_equal(a[0], b[0]) and a[1:] == b[1:], (mode, layout)
+        assert a[1] > 0 and np.isfinite(a[0]).all()
+
+
 def test_importance_pyramid_is_bit_identical(oracle):
     """vx_upload_environment builds the 512^2 importance map + mips on the device: same bits as the
     oracle for the default checkerboard and for a random HDR-like map"""

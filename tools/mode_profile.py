@@ -10,6 +10,6 @@ r.settings.bounces = int(sys.argv[2]) if len(sys.argv) > 2 else 1
 r.settings.max_samples = 1 << 30
 r.bind_uniforms()
 r.render(frames=2, rebind=False); r.finish(); r.reset_counters()
-r.render(frames=64, rebind=False, in_flight=32); r.finish()
+r.render(frames=32, rebind=False, in_flight=16); r.finish()
 c = r.counters()
 print(mode, "ms/frame", c.kernel_ms / c.frames, "Msamples", c.samples / c.frames / 1e6)

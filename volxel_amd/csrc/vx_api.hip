@@ -13,6 +13,7 @@
 #include "vx_dvr.hpp"
 #include "vx_dvr_lds.hpp"
 #include "vx_kernels.hpp"
+#include "vx_paths.hpp"
 
 using namespace vx;
 
@@ -97,6 +98,8 @@ struct VxContext {
     max_launch_frames = n > max_launch_frames ? n : max_launch_frames;
   }
   int dvr_variant = -1;  // -1: tuned kernel; 0: generic
+  int paths_variant = 0;   // 0: one pixel per lane (render_generic); 1: path segments re-packed through LDS
+                           // (vx_paths.hpp, VX_PATHS_KERNEL=packed) -- same bits, measured 3-11 % slower
 
   // frame pipelining (vx_render_frames): independent accumulation frames in flight on their own
   // streams, each into its own result slab + counter records; blended in order afterwards
@@ -395,8 +398,31 @@ static void launch_generic(VxContext* c, const MultiOut& mo, float weight, dim3 
                        c->dv, c->tf, c->tf_len, mo, weight, c->tm);
 }
 
+// the three reference modes with the path segments re-packed through LDS (vx_paths.hpp)
+template <int MODE>
+static void launch_paths(VxContext* c, const MultiOut& mo, float weight, dim3 grid, size_t lds, hipStream_t stream) {
+  grid.x *= mo.count ? mo.count : 1u;
+  if (c->layout == VX_LAYOUT_BRICKF32)
+    hipLaunchKernelGGL((render_paths<MODE, LAYOUT_BF>), grid, dim3(256), lds, stream, c->params, c->dv, c->tf, c->tf_len,
+                       mo, weight, c->tm);
+  else if (c->layout == VX_LAYOUT_CELLQUAD)
+    hipLaunchKernelGGL((render_paths<MODE, LAYOUT_CQ>), grid, dim3(256), lds, stream, c->params, c->dv, c->tf, c->tf_len,
+                       mo, weight, c->tm);
+  else
+    hipLaunchKernelGGL((render_paths<MODE, LAYOUT_REF>), grid, dim3(256), lds, stream, c->params, c->dv, c->tf, c->tf_len,
+                       mo, weight, c->tm);
+}
+
 static void launch_generic_mode(VxContext* c, const MultiOut& mo, float weight, dim3 grid, hipStream_t stream) {
   size_t lds = c->tf_len <= TF_LDS_MAX ? (size_t)c->tf_len * sizeof(float4) : 0;
+  if (c->paths_variant != 0 && !c->params.debug_hits && c->params.render_mode <= VX_MODE_RAYMARCH) {
+    switch (c->params.render_mode) {
+      case VX_MODE_DEFAULT: launch_paths<VX_MODE_DEFAULT>(c, mo, weight, grid, lds, stream); break;
+      case VX_MODE_NO_DDA: launch_paths<VX_MODE_NO_DDA>(c, mo, weight, grid, lds, stream); break;
+      default: launch_paths<VX_MODE_RAYMARCH>(c, mo, weight, grid, lds, stream); break;
+    }
+    return;
+  }
   switch (c->params.render_mode) {
     case VX_MODE_DEFAULT: launch_generic<VX_MODE_DEFAULT>(c, mo, weight, grid, lds, stream); break;
     case VX_MODE_NO_DDA: launch_generic<VX_MODE_NO_DDA>(c, mo, weight, grid, lds, stream); break;
@@ -434,6 +460,8 @@ int vx_create(int device_id, VxContext** out) {
   c->stream = c->own_stream;
   const char* v = getenv("VX_DVR_KERNEL");
   if (v && !strcmp(v, "generic")) c->dvr_variant = 0;
+  const char* pk = getenv("VX_PATHS_KERNEL");
+  if (pk && !strcmp(pk, "packed")) c->paths_variant = 1;
   const char* dpe = getenv("VX_DVR_DP");
   if (dpe) c->dp_env = atoi(dpe);
   const char* o = getenv("VX_DVR_ORDER");
@@ -545,6 +573,24 @@ static int build_layout_layers(VxContext* c, uint32_t z0, uint32_t z1, hipStream
                          (float4*)c->cq_alloc, at, at + n);
       at += n;
     }
+  }
+  VX_HIP(c, hipGetLastError());
+  return VX_OK;
+}
+
+// dvr_phong runs on the LDS-window kernel, which samples the brickf32 layout: a context whose primary layout is
+// cellquad gets the 4-byte-per-voxel brick layout built beside it the first time Phong is rendered
+static int ensure_brickf32(VxContext* c) {
+  if (c->dv.bf) return VX_OK;
+  const uint64_t n_vox = (uint64_t)c->dv.bc[0] * c->dv.bc[1] * c->dv.bc[2] * 512u;
+  if (n_vox / 4u > 0xffffffffull) return VX_OK;   // too large: the generic kernel serves Phong
+  VX_HIP(c, hipMalloc(&c->bf_alloc, n_vox * sizeof(float)));
+  c->dv.bf = (const float*)c->bf_alloc;
+  for (uint64_t at = 0; at < n_vox;) {
+    uint64_t n = n_vox - at < (1ull << 31) ? n_vox - at : (1ull << 31);
+    hipLaunchKernelGGL(build_brickf32, dim3((uint32_t)((n + 255) / 256)), dim3(256), 0, c->stream, c->dv,
+                       (float*)c->bf_alloc, at, at + n);
+    at += n;
   }
   VX_HIP(c, hipGetLastError());
   return VX_OK;
@@ -873,6 +919,20 @@ int vx_resize(VxContext* c, uint32_t w, uint32_t h) {
   return alloc_framebuffers(c);
 }
 
+static bool tuned_possible(const VxContext* c) {
+  return c->dvr_variant != 0 && !c->params.debug_hits && c->tf_len <= TF_LDS_MAX;
+}
+// the LDS-window kernel (vx_dvr_lds.hpp): DVR on the brickf32 layout, Phong wherever brickf32 data is resident
+static bool use_lds_kernel(const VxContext* c) {
+  if (!tuned_possible(c)) return false;
+  if (c->params.render_mode == VX_MODE_DVR) return c->layout == VX_LAYOUT_BRICKF32;
+  return c->params.render_mode == VX_MODE_DVR_PHONG && c->dv.bf != nullptr;
+}
+static bool is_tuned(const VxContext* c) {
+  const bool dvr_cq = c->params.render_mode == VX_MODE_DVR && c->layout == VX_LAYOUT_CELLQUAD;
+  return tuned_possible(c) && (dvr_cq || use_lds_kernel(c));
+}
+
 static int prepare_render(VxContext* c, dim3& grid) {
   if (!c->has_volume) VX_FAIL(c, VX_ERR_NO_VOLUME, "vx_render_frame: no volume uploaded");
   if (!c->has_params) VX_FAIL(c, VX_ERR_INVALID, "vx_render_frame: vx_set_params not called");
@@ -900,22 +960,20 @@ static int prepare_render(VxContext* c, dim3& grid) {
       }
     }
   }
+  if (c->params.render_mode == VX_MODE_DVR_PHONG && c->layout == VX_LAYOUT_CELLQUAD && tuned_possible(c)) {
+    int rc = ensure_brickf32(c);
+    if (rc) return rc;
+  }
   uint32_t groups = (c->tm.tiles_per_shard + 7u) / 8u;
   grid = dim3(groups * 128u);
   return ensure_counters(c, (size_t)grid.x * 4u * 8u);  // x8: the depth-parallel DVR grid
-}
-
-static bool is_tuned(const VxContext* c) {
-  const bool dvr = c->params.render_mode == VX_MODE_DVR && c->layout != VX_LAYOUT_REFERENCE;
-  const bool phong = c->params.render_mode == VX_MODE_DVR_PHONG && c->layout == VX_LAYOUT_BRICKF32;
-  return (dvr || phong) && c->dvr_variant != 0 && !c->params.debug_hits && c->tf_len <= TF_LDS_MAX;
 }
 
 // one render-kernel launch into `out` (accumulator or a pipeline result slab)
 static hipError_t launch_render(VxContext* c, uint32_t frame_index, float weight, dim3 grid, float4* out,
                                 DevCounters* dc, hipStream_t stream) {
   bool tuned = is_tuned(c);
-  if (tuned && c->layout == VX_LAYOUT_BRICKF32) {
+  if (tuned && use_lds_kernel(c)) {
     MultiOut mo{};
     mo.count = 1;
     mo.out[0] = out;
@@ -963,7 +1021,7 @@ int vx_render_frame(VxContext* c, uint32_t frame_index, float sample_weight) {
   VX_HIP(c, hipEventRecord(ev.a, c->stream));
   hipError_t le = launch_render(c, frame_index, sample_weight, grid, c->slab, c->dc, c->stream);
   VX_HIP(c, hipEventRecord(ev.b, c->stream));
-  const bool ordered = is_tuned(c) && c->use_order && !(c->dp_active() && c->layout == VX_LAYOUT_CELLQUAD);
+  const bool ordered = is_tuned(c) && c->use_order && !(c->dp_active() && !use_lds_kernel(c));
   if (!ordered) c->order_builds_left = 0;
   if (ordered && le == hipSuccess && c->order_builds_left > 0) {
     c->order_builds_left--;
@@ -1034,8 +1092,8 @@ int vx_render_frames(VxContext* c, uint32_t first_frame, uint32_t count, const f
   if ((rc = take_events(c, ev))) return rc;
   ev.launches = count - done;
   hipError_t le = hipSuccess;
-  const bool tuned_cq = is_tuned(c) && c->layout == VX_LAYOUT_CELLQUAD && !c->dp_active();
-  const bool tuned_lds = is_tuned(c) && c->layout == VX_LAYOUT_BRICKF32;
+  const bool tuned_lds = is_tuned(c) && use_lds_kernel(c);
+  const bool tuned_cq = is_tuned(c) && !tuned_lds && !c->dp_active();
   if (tuned_cq || tuned_lds || !is_tuned(c)) {
     // several frames per launch (see MultiOut): one kernel for up to in_flight frames, then the
     // ordered blend of their results (the tuned cellquad DVR kernel and every render_generic mode)
@@ -1400,7 +1458,7 @@ int vx_probe_gather_spread(VxContext* c, uint32_t frame_index, uint64_t out3[3])
   dim3 grid;
   int rc = prepare_render(c, grid);
   if (rc) return rc;
-  if (!(is_tuned(c) && c->layout == VX_LAYOUT_CELLQUAD))
+  if (!(is_tuned(c) && c->layout == VX_LAYOUT_CELLQUAD && c->params.render_mode == VX_MODE_DVR))
     VX_FAIL(c, VX_ERR_INVALID, "vx_probe_gather_spread: needs render_mode dvr on the cellquad layout");
   const size_t waves = (size_t)grid.x * 4u;
   DevCounters* d = nullptr;

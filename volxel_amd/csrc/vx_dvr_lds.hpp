@@ -5,15 +5,15 @@
 //
 // Why LDS: the cellquad kernel (vx_dvr.hpp) is bound by the vector L1's tag pipe -- the 64 lanes of a gather touch
 // ~10 distinct 128-byte lines but the L1 works on groups of 4 lanes and spends ~30 look-ups on them (bench.py
-// roofline.l1).  Here a wave fetches every voxel of its window ONCE with row-coalesced 16-byte loads (8 load
-// instructions per window instead of 2 per march step) and then takes the eight taps of a sample -- and the 24
+// roofline.l1).  Here a wave fetches every voxel of its window ONCE with row-coalesced 16-byte loads (3 load
+// instructions per window of ~16 march steps instead of 2 per march step) and then takes the eight taps of a sample -- and the 24
 // further taps of a gradient -- from LDS, which has no tags.
 //
 // One wave = one 8x8-pixel tile, as everywhere.  Per window:
 //   1. anchor: the window is DIMX x DIMY x DIMZ voxels; per axis it starts at the smallest cell any live lane
 //      samples next (largest, if the wave marches in the negative direction), x rounded down to a multiple of 4;
-//   2. stage: lane = one (y,z) row of the window: up to 4 aligned 16-byte loads from the brick rows it crosses,
-//      all issued back to back, then 4 ds_write_b128; rows and chunks outside the volume are zeros (A4);
+//   2. stage: lane = one (y,z) row of the window: X / 4 aligned 16-byte loads from the brick rows it crosses,
+//      all issued back to back, then as many ds_write_b128; rows and chunks outside the volume are zeros (A4);
 //   3. march: up to S steps; a lane takes a step while the cell of its next sample (and, for Phong, the cells one
 //      voxel either side) lies inside the window, otherwise it waits for the next window.  Lanes advance at their
 //      own pace -- every ray still evaluates exactly its own sample sequence, so densities, TF bins, sample counts
@@ -24,27 +24,42 @@
 
 namespace vx {
 
-// Window geometry.  X voxels per row are staged as four aligned 16-byte chunks; a row occupies RS words of LDS and a
-// z slice SS words.  RS = 20 and SS = 28 (mod 32) spread the lanes of a read over the 32 banks: RS steps rows by
-// 20 banks (eight consecutive rows land on eight different 4-bank groups), SS steps slices by 28.  With the natural
-// strides (16, 160) rows two apart and ALL slices alias: profiles/r02_lds_v1 shows the LDS spending a third of the
-// kernel time in bank conflicts.
+// Window geometry (measured on config 3 / 4, 1x MI355X, 16 frames per launch, ms per frame DVR / Phong:
+//   X 16, D 10 / 12, natural strides (16, 160)        0.498 / 0.838   a third of the time in LDS bank conflicts
+//   X 16, D 9 / 10, strides (20, 188 / 220)            0.485 / 0.670   (+ hardware transcendentals in the shading)
+//   X 16, D 8 / 10                                      0.453 / 0.664   64 rows = ONE staging pass, 6 blocks per CU
+//   X 12, D 8 / 10                                      0.438 / 0.614   three chunks per row instead of four
+//   X 12, D 8 / 11 (shipped)                            0.438 / 0.591
+//   D 10 for DVR 0.534, S 12 / 20 / 24 / 32 steps per window 0.446 / 0.462 / 0.487 / 0.496 (S = 16: 0.438)).
+// X voxels per row are staged as aligned 16-byte chunks; a row occupies RS words of LDS and a z slice SS words.
+// RS = 4 (mod 8) and SS = 28 (mod 32) spread the lanes of a read over the 32 banks: eight consecutive rows land on
+// eight different 4-bank groups, slices step by 28 banks.  (-DVX_LDS_X / _D / _DP / _S rebuild a variant:
+// tools/variant_build.sh.)
+#ifndef VX_LDS_D
+#define VX_LDS_D 8
+#endif
+#ifndef VX_LDS_DP
+#define VX_LDS_DP 11
+#endif
+#ifndef VX_LDS_X
+#define VX_LDS_X 12
+#endif
+#ifndef VX_LDS_S
+#define VX_LDS_S 16
+#endif
 template <bool PHONG>
 struct LdsTile {
-  static constexpr int X = 16;                   // four 16-byte chunks per row
-  static constexpr int Y = PHONG ? 10 : 9;
-  static constexpr int Z = PHONG ? 10 : 9;
-  static constexpr int RS = 20;                  // row stride in words
-#ifndef VX_LDS_SS_PAD
-#define VX_LDS_SS_PAD 0
-#endif
-  static constexpr int SS = (PHONG ? 220 : 188) + VX_LDS_SS_PAD;   // slice stride in words: >= Y * RS, = 28 mod 32, multiple of 4
+  static constexpr int X = VX_LDS_X;             // X / 4 chunks of 16 bytes per row
+  static constexpr int Y = PHONG ? VX_LDS_DP : VX_LDS_D;
+  static constexpr int Z = PHONG ? VX_LDS_DP : VX_LDS_D;
+  static constexpr int RS = (X % 8 == 4) ? X : X + 4;             // row stride in words, = 4 mod 8
+  static constexpr int SS = (Y * RS + 31 - 28) / 32 * 32 + 28;    // slice stride in words: >= Y * RS, = 28 mod 32
   static constexpr int ROWS = Y * Z;
-  static constexpr int FLOATS = SS * Z;          // 6768 B (DVR) / 8800 B (Phong) per wave
+  static constexpr int FLOATS = SS * Z;          // 3968 B (DVR) / 6864 B (Phong) per wave
   static constexpr int PASSES = (ROWS + 63) / 64;
   static constexpr int LO_MARGIN = PHONG ? 1 : 0;   // cells below the sample's cell that must be resident
   static constexpr int HI_MARGIN = PHONG ? 2 : 1;   // taps above it (x+1; x+2 for the gradient)
-  static_assert(SS >= Y * RS && SS % 4 == 0 && RS % 4 == 0 && RS >= X, "tile strides");
+  static_assert(SS >= Y * RS && SS % 4 == 0 && RS % 4 == 0 && RS >= X && X % 4 == 0, "tile strides");
 };
 
 // ---- wave64 integer min / max with DPP (row scan + row broadcasts), result in every lane ----
@@ -191,15 +206,16 @@ __global__ __launch_bounds__(256) void render_dvr_lds(const VxParams p, const De
     __builtin_amdgcn_wave_barrier();
     {
       // chunk c covers x = LOx + 4c .. +3: brick column and offset inside the brick row are wave uniform
-      uint32_t xoff[4];
-      bool xin[4];
+      constexpr int NC = DX / 4;
+      uint32_t xoff[NC];
+      bool xin[NC];
 #pragma unroll
-      for (int c = 0; c < 4; ++c) {
+      for (int c = 0; c < NC; ++c) {
         const int gx = LOx + 4 * c;
         xin[c] = (uint32_t)gx < ex;
         xoff[c] = (((uint32_t)gx >> 3) << 7) + (((uint32_t)gx & 7u) >> 2);   // brick x * 128 + half row (16-byte units)
       }
-      float4 vals[TL::PASSES][4];
+      float4 vals[TL::PASSES][NC];
 #pragma unroll
       for (int ps = 0; ps < TL::PASSES; ++ps) {
         const uint32_t row = lane + 64u * (uint32_t)ps;
@@ -210,7 +226,7 @@ __global__ __launch_bounds__(256) void render_dvr_lds(const VxParams p, const De
         const uint32_t rowbase = ((((uint32_t)gz >> 3) * bcy + ((uint32_t)gy >> 3)) * bcx << 7) +
                                  ((((uint32_t)gz & 7u) << 4) | (((uint32_t)gy & 7u) << 1));
 #pragma unroll
-        for (int c = 0; c < 4; ++c) {
+        for (int c = 0; c < NC; ++c) {
           float4 val = make_float4(0.f, 0.f, 0.f, 0.f);
 #ifndef VX_LDS_EXP_NOLOAD   // timing experiment only: no global loads
           if (rin && xin[c]) val = bf4[rowbase + xoff[c]];
@@ -227,10 +243,10 @@ __global__ __launch_bounds__(256) void render_dvr_lds(const VxParams p, const De
           const uint32_t zz = row / (uint32_t)DY, yy = row - zz * (uint32_t)DY;
           float4* dst = reinterpret_cast<float4*>(tile + zz * (uint32_t)SS + yy * (uint32_t)RS);
 #pragma unroll
-          for (int c = 0; c < 4; ++c) dst[c] = vals[ps][c];
+          for (int c = 0; c < NC; ++c) dst[c] = vals[ps][c];
         }
       }
-      n_loads += 4u * (uint32_t)TL::PASSES;
+      n_loads += (uint32_t)NC * (uint32_t)TL::PASSES;
     }
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     __builtin_amdgcn_wave_barrier();
@@ -347,7 +363,7 @@ inline void launch_dvr_lds(const VxParams& p, const DevVolume& v, const float4* 
   const bool phong = p.render_mode == VX_MODE_DVR_PHONG;
   const size_t tile_bytes = 4u * (size_t)(phong ? LdsTile<true>::FLOATS : LdsTile<false>::FLOATS) * sizeof(float);
   const size_t lds = (size_t)tf_len * sizeof(float4) + (skip ? (((size_t)v.skip_words + 3u) & ~(size_t)3u) * 4u : 0u) + tile_bytes;
-  constexpr int S = 16;
+  constexpr int S = VX_LDS_S;
 #define VX_LAUNCH_LDS(PH, SK) \
   hipLaunchKernelGGL((render_dvr_lds<S, PH, SK>), grid, block, lds, stream, p, v, tf, tf_len, mo, weight, tm, order)
   if (phong) {
