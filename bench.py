@@ -14,14 +14,17 @@ of the slab so that it overlaps the next frames.  Strong scaling: the frame is f
 of all ranks / max-over-ranks time.
 
 Prints ONE JSON line on rank 0 (contract in the task statement).  Besides the contract keys:
-  roofline      the dominant kernel (vx::render_dvr_cq<4>): ALGORITHMIC bytes of the launches actually
+  roofline      the dominant kernel (vx::render_dvr_lds<16>; --layout 1: vx::render_dvr_cq<4>): ALGORITHMIC bytes of the launches actually
                 timed (16 B per sample, SURVEY 8(d), + 16 B per pixel per frame for the result the kernel
                 writes) / their mean HIP-event duration, against the 8 TB/s HBM peak; `traffic` = HBM bytes
                 per launch from the rocprofv3 PMC passes of this same command when profiles/traffic.json
                 holds them for exactly this launch shape, else null; `blend` = the merge kernel
                 (fragment.frag:158 applied in order), timed apart; `frames_per_launch_1` = the same
                 measurement with one frame per launch;
-  roofline.l1   the limiter the counters name (the vector L1 / texture path): gather instructions counted by
+  roofline.issue  the limiter the counters name for the shipped LDS-window kernel: vector-ALU issue -- clocks per wave
+                step per CU (live) against VALU instructions per wave step (rocprofv3) x the device's measured clocks per
+                instruction (vx_probe_valu_rate, this run);
+  roofline.l1   (--layout 1, the cellquad gather kernel) the vector L1 / texture path: gather instructions counted by
                 the kernel, distinct 128-byte lines per gather counted by a probe build of the same kernel,
                 clocks per gather per CU, and the floor the L1 sustains for that many line look-ups with no
                 arithmetic at all (vx_probe_gather_rate, measured in this run);
@@ -44,8 +47,8 @@ BYTES_PER_PIXEL_RESULT = 16.0   # RGBA32F result written by the render kernel (o
 BYTES_PER_PIXEL_BLEND = 32.0    # accumulator read + write by the blend (+32 B per pixel per frame
                                 # = this + nothing else when a frame is blended in the render kernel itself)
 DEFAULT_FRAMES_PER_LAUNCH = 16
-KERNEL = {None: "vx::render_dvr_cq<4>", 0: "vx::render_generic<3,0>", 1: "vx::render_dvr_cq<4>", 2: "vx::render_dvr_tile<8>"}
-LAYOUT = {None: "cellquad", 0: "reference", 1: "cellquad", 2: "brickf32"}
+KERNEL = {None: "vx::render_dvr_lds<16>", 0: "vx::render_generic<3,0>", 1: "vx::render_dvr_cq<4>", 2: "vx::render_dvr_lds<16>"}
+LAYOUT = {None: "brickf32", 0: "reference", 1: "cellquad", 2: "brickf32"}   # None = VX_LAYOUT_AUTO: DVR marches brickf32
 
 
 def build_scene(width, height, n_vox, rank, world, device):
@@ -125,7 +128,7 @@ def traffic_from_profile(a, frames_per_launch, jitter):
         for t in json.load(open(path)).get(LAYOUT[a.layout], []):
             if (t["width"], t["height"], t["volume"], t["frames_per_launch"], bool(t["dvr_jitter"])) == \
                     (a.width, a.height, a.volume, frames_per_launch, bool(jitter)):
-                return {"traffic": int(t["hbm_bytes_per_launch"]), "traffic_source": t["source"]}
+                return {"traffic": int(t["hbm_bytes_per_launch"]), "traffic_source": t["source"], "_entry": t}
     except Exception:
         pass
     return {"traffic": None}
@@ -159,6 +162,46 @@ def l1_block(r, c, clock_khz_hint=None):
                     "straddle a line would reach"}
 
 
+VALU_CLK_PER_INST = 2.0   # MI355X_MICROARCH.md: a wave64 VALU instruction issues over 2 cycles of a SIMD-32
+
+
+def issue_block(r, c, entry):
+    """the limiter of the LDS-window kernel: vector-ALU issue.  Live: wave steps (a wave taking one march step), staging
+    loads and LDS tap reads counted by the kernel.  From the rocprofv3 PMC pass of this same command
+    (profiles/traffic.json, only for exactly this launch shape): the VALU instructions the kernel issues per launch.
+    floor = those instructions at the architectural issue rate (one wave64 instruction per 2 clocks per SIMD, 4 SIMDs
+    per CU); the clocks are nominal (the chip runs this kernel at ~2.3 GHz, GRBM_GUI_ACTIVE in the same profile)."""
+    if not c.lane_slots or not c.kernel_ms:
+        return None
+    name, cus, mem = r.device_info()
+    fma_clk, khz = r.probe_valu_rate()
+    launches = max(c.launches, 1)
+    steps = c.lane_slots / 64
+    clk = (c.kernel_ms * 1e-3) * (khz * 1e3) * cus / steps
+    out = {"bound": "valu", "unit": "clk per wave step (64 lanes x one march step) per CU at the nominal clock",
+           "nominal_clock_mhz": round(khz / 1e3, 1),
+           "wave_steps": int(steps // launches), "staging_loads_per_wave_step": round(c.gathers / steps, 4),
+           "lds_tap_reads_per_wave_step": round(c.lds_reads / steps, 3),
+           "clk_per_wave_step_per_cu": round(clk, 2),
+           "valu_insts_per_wave_step": None, "clk_per_valu_inst_per_simd": None, "floor_clk": None, "frac": None,
+           "pure_fma_stream_clk_per_inst_per_simd": round(fma_clk, 2),
+           "note": "floor_clk = VALU instructions per wave step (rocprofv3 SQ_INSTS_VALU of this same command / wave steps) "
+                   "x 2 clk / 4 SIMDs; frac = floor / measured; pure_fma_stream = what a stream of independent v_fma_f32 "
+                   "reaches on this device in this run (8 waves per SIMD; it is power-limited, so not a ceiling for a mixed stream)"}
+    if entry and entry.get("sq_insts_valu_per_launch"):
+        per_step = entry["sq_insts_valu_per_launch"] / (steps / launches)
+        floor = per_step * VALU_CLK_PER_INST / 4.0
+        out.update({"valu_insts_per_wave_step": round(per_step, 1), "clk_per_valu_inst_per_simd": round(clk * 4.0 / per_step, 2),
+                    "floor_clk": round(floor, 2), "frac": round(floor / clk, 4),
+                    "valu_source": entry["source"].split(" (")[0]})
+        if entry.get("effective_clock_mhz"):
+            # the clock the chip actually held while running this kernel (GRBM_GUI_ACTIVE / 8 XCDs / traced duration)
+            eff = entry["effective_clock_mhz"]
+            out.update({"effective_clock_mhz": round(eff, 0),
+                        "frac_at_effective_clock": round(floor / (clk * eff * 1e3 / khz), 4)})
+    return out
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -168,7 +211,9 @@ def main():
     ap.add_argument("--height", type=int, default=1080)
     ap.add_argument("--volume", type=int, default=512)
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--layout", type=int, default=None, help="0 reference, 1 cellquad (default), 2 brickf32 + LDS tiles")
+    ap.add_argument("--layout", type=int, default=None,
+                    help="0 reference, 1 cellquad (gather kernel), 2 brickf32 (LDS-window kernel); default: the library's "
+                         "VX_LAYOUT_AUTO, which marches DVR on brickf32")
     ap.add_argument("--gather-every", type=int, default=64,
                     help="N>1: all_gather the framebuffer once per this many accumulation frames")
     ap.add_argument("--frames-per-launch", type=int, default=DEFAULT_FRAMES_PER_LAUNCH,
@@ -309,10 +354,12 @@ def main():
         avg_kernel_s = c.kernel_ms / launches / 1e3
         achieved = alg_bytes_launch / avg_kernel_s / 1e9 if avg_kernel_s > 0 else 0.0
         fpl = int(c.max_launch_frames)
+        prof = traffic_from_profile(a, fpl, r.settings.dvr_jitter)
+        prof_entry = prof.pop("_entry", None)
         roof = {
             "bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
             "frac": round(achieved / HBM_PEAK_GBS, 4),
-            **traffic_from_profile(a, fpl, r.settings.dvr_jitter),
+            **prof,
             "kernel": KERNEL[a.layout],
             "avg_kernel_ms": round(c.kernel_ms / launches, 4), "launches": int(c.launches), "frames": int(c.frames),
             "frames_per_launch": fpl, "min_frames_per_launch": int(c.min_launch_frames),
@@ -374,8 +421,10 @@ def main():
                 "achieved": round(alg1 / k1 / 1e9, 1), "frac": round(alg1 / k1 / 1e9 / HBM_PEAK_GBS, 4),
                 "algorithmic_model": "16 B/sample + 32 B/pixel/frame (accumulator read + write in the same kernel)"}
             # (2) the limiter the counters name
-            if a.layout in (None, 1):
-                roof["l1"] = l1_block(r, c)
+            if a.layout == 1:
+                roof["l1"] = l1_block(r, c)       # the cellquad gather kernel: vector L1 tag pipe
+            elif a.layout in (None, 2):
+                roof["issue"] = issue_block(r, c, prof_entry)   # the LDS-window kernel: vector-ALU issue
         if world == 1 and not a.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(r, msg)
         else:

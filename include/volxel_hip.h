@@ -44,15 +44,19 @@ enum VxRenderMode {
   VX_MODE_DVR_PHONG = 4 /* [build] DVR + central-difference gradient + Phong (config 4)  */
 };
 
-/* device layout of the brick grid used by the trilinear modes */
+/* device layout of the brick grid the trilinear look-ups sample (vx_set_layout) */
 enum VxLayout {
   VX_LAYOUT_REFERENCE = 0, /* the three reference textures, linear buffers (common.glsl:35-43) */
-  VX_LAYOUT_CELLQUAD = 1,  /* MI355X native (default): apron bricks of pre-decoded fp32
-                              xy-quads, two 16-byte gathers per sample, batches of 4 steps
-                              in flight per wave                                          */
-  VX_LAYOUT_BRICKF32 = 2   /* MI355X native: 8^3 bricks decoded to fp32, 2 KiB contiguous each;
-                              the DVR kernel stages the active tile of voxels per wave
-                              through LDS (4x less memory than cellquad, currently slower) */
+  VX_LAYOUT_CELLQUAD = 1,  /* MI355X native: apron bricks of pre-decoded fp32 xy-quads (18 bytes per
+                              voxel), two 16-byte gathers per trilinear look-up; the DVR kernel keeps
+                              batches of 4 steps in flight per wave                              */
+  VX_LAYOUT_BRICKF32 = 2,  /* MI355X native: 8^3 bricks decoded to fp32, 2 KiB contiguous each (4 bytes
+                              per voxel); the DVR / Phong kernel stages the window of voxels a wave is
+                              marching through into LDS and takes every tap from there           */
+  VX_LAYOUT_AUTO = 3       /* default: each render mode on the layout its kernels are fastest on -- DVR and
+                              DVR + Phong on BRICKF32 (built at upload), the path-traced reference modes on
+                              CELLQUAD (built the first time such a mode is rendered); volumes beyond the index
+                              range of a layout fall back to REFERENCE for the modes concerned       */
 };
 
 /*
@@ -188,7 +192,7 @@ int vx_upload_stats(VxContext* ctx, double* seconds, uint64_t* host_bytes, int* 
 struct VxBrickGrid;
 int vx_upload_brick_grid(VxContext* ctx, const struct VxBrickGrid* grid);
 
-/* select the device layout the trilinear modes sample from (default VX_LAYOUT_CELLQUAD);
+/* select the device layout the trilinear modes sample from (default VX_LAYOUT_AUTO);
  * takes effect at the next vx_upload_volume or immediately if a volume is resident. */
 int vx_set_layout(VxContext* ctx, int layout);
 
@@ -289,6 +293,10 @@ int vx_debug_rng(VxContext* ctx, int op, const uint32_t* a, const uint32_t* b, u
  * per CU, 8 gathers in flight per wave.  Returns the cost in clocks per gather instruction per CU at
  * the device's nominal clock (clock_khz_out).  bench.py calls it for the roofline.l1 block. */
 int vx_probe_gather_rate(VxContext* ctx, uint32_t lines, double* clk_per_gather_out, uint32_t* clock_khz_out);
+/* measurement hook: what the vector ALUs of this device sustain: clocks (nominal clock) per wave64 VALU instruction per
+ * SIMD, from independent v_fma_f32 chains at 8 waves per SIMD.  bench.py prices the instruction count of the LDS-window
+ * DVR kernel with it (roofline.issue). */
+int vx_probe_valu_rate(VxContext* ctx, double* clk_per_instruction_out, uint32_t* clock_khz_out);
 /* measurement hook: re-march frame `frame_index` with the current volume / params and count, per gather
  * instruction of the tuned cellquad DVR kernel, the distinct 128-byte lines its active lanes address
  * (whole wave) and the line look-ups of its 16 groups of 4 consecutive lanes (what the L1 tag pipe sees).

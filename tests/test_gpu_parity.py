@@ -694,7 +694,7 @@ def test_counters_report_the_launches_that_ran(oracle):
     from volxel_amd import Volxel3DRenderer, synth
     vox, sp = synth.value_noise(64, seed=2, zero_quantile=0.4)
     g = oracle.BrickGrid(vox, sp)
-    r = Volxel3DRenderer(192, 128)
+    r = Volxel3DRenderer(192, 128, layout=1)                  # the cellquad gather kernel and its probes
     r.setup_from_grid(g)
     r.change_transfer_func(*benchmark_tf())
     r.settings.render_mode = "dvr"
@@ -723,6 +723,20 @@ def test_counters_report_the_launches_that_ran(oracle):
     clk1, _ = r.probe_gather_rate(1)
     clk64, _ = r.probe_gather_rate(64)
     assert khz >= 1000000 and 10.0 < clk1 <= clk < clk64 < 400.0
+    r.close()
+    # the default layout (VX_LAYOUT_AUTO) marches DVR through LDS windows: staging loads and LDS tap reads are counted
+    r = Volxel3DRenderer(192, 128)
+    r.setup_from_grid(g)
+    r.change_transfer_func(*benchmark_tf())
+    r.settings.render_mode = "dvr"
+    r.settings.dvr_skip_empty = False
+    r.render(frames=2); r.finish(); r.reset_counters()
+    r.render(frames=5, rebind=False, in_flight=5); r.finish()
+    c = r.counters()
+    steps = c.lane_slots // 64
+    assert (c.launches, c.max_launch_frames) == (1, 5) and c.lds_reads == 4 * steps and 0 < c.gathers < steps
+    with pytest.raises(Exception, match="cellquad"):
+        r.probe_gather_spread(0)
     r.close()
 
 
@@ -812,7 +826,7 @@ def test_balanced_tile_order_is_bit_identical_and_levels_the_shards(big_scene):
     from volxel_amd import Volxel3DRenderer, tiles
     from volxel_amd.dist import slab_tensor
     r, msg = big_scene
-    r.set_layout(1)                             # the shard contexts below use the default layout and kernel too
+    r.set_layout(3)                             # VX_LAYOUT_AUTO: the shard contexts below use the default layout and kernel too
     r.restart_rendering(); r.render(frames=3, in_flight=1); base = r.read_accum()
     N = 8
     perms, slabs, per_rank, plain = [], [], [], []
@@ -879,8 +893,8 @@ def huge_scene():
 
 
 def test_config5_1024_cubed_4k_eight_tile_shards(huge_scene):
-    """the 19.8 GB cellquad build, the 24-bit brick index arithmetic of the march, the 2040-tile dealing order and
-    the multi-frame launch at their full size (brick.rs:77-81 sets the limits): every one of the 8 shards, dealt
+    """the brickf32 / LDS-window march, the 19.8 GB cellquad build, the 24-bit brick index arithmetic of the gather
+    march, the 2040-tile dealing order and the multi-frame launch at their full size (brick.rs:77-81 sets the limits): every one of the 8 shards, dealt
     by the balanced order, reproduces its pixels of the unsharded 4K frame bit for bit; sample counts add up;
     the tuned kernel equals the generic kernel on the reference layout"""
     import torch
@@ -899,13 +913,15 @@ def test_config5_1024_cubed_4k_eight_tile_shards(huge_scene):
     r.restart_rendering(); r.reset_counters()
     r.render(frames=3, in_flight=3)
     assert np.array_equal(r.read_accum(), base) and r.counters().samples == c0.samples
-    # tuned cellquad kernel vs the generic kernel on the reference textures (every tap through range ->
-    # pointer -> atlas): same sample count, image within the exp tolerance
-    r.set_layout(0); r.restart_rendering(); r.reset_counters(); r.render(frames=3, in_flight=1)
-    ref = r.read_accum(); c1 = r.counters()
-    assert c1.samples == c0.samples and c1.rays == c0.rays
-    assert np.abs(ref - base).max() <= 2e-6
-    r.set_layout(1)
+    # the default layout marches through LDS windows of the 4.3 GB brickf32 layout; the cellquad gather kernel
+    # (19.8 GB build, 24-bit brick index arithmetic) and the generic kernel on the reference textures (every tap
+    # through range -> pointer -> atlas) evaluate the same samples: same count, image within the exp tolerance
+    for layout in (1, 0):
+        r.set_layout(layout); r.restart_rendering(); r.reset_counters(); r.render(frames=3, in_flight=1)
+        ref = r.read_accum(); c1 = r.counters()
+        assert c1.samples == c0.samples and c1.rays == c0.rays, layout
+        assert np.abs(ref - base).max() <= 2e-6, layout
+    r.set_layout(3)
     # 8 shards through ONE extra context (re-sharded in place; the volume is replicated per GPU in production)
     N = 8
     rr = Volxel3DRenderer(3840, 2160, shard_rank=0, shard_count=N)
@@ -952,7 +968,7 @@ def test_volume_beyond_the_cellquad_index_range_is_refused(oracle):
         range_mipmaps=[(np.zeros(2 * (b >> k) ** 3, dtype=np.uint16), (b >> k, b >> k, b >> k)) for k in (1, 2, 3)],
         index_extent=(b * 8, b * 8, b * 8), min_maj=(0.0, 1.0),
         transform=np.eye(4, dtype=np.float32).reshape(-1))
-    r = Volxel3DRenderer(64, 64)
+    r = Volxel3DRenderer(64, 64, layout=1)
     with pytest.raises(VolxelError, match="too large for the cellquad layout"):
         r.setup_from_grid(msg)
     with pytest.raises(VolxelError, match="without a volume|no volume"):
@@ -962,6 +978,12 @@ def test_volume_beyond_the_cellquad_index_range_is_refused(oracle):
     r.settings.render_mode = "dvr"
     r.render(); img = r.read_accum()
     assert np.isfinite(img).all()
+    # the default (VX_LAYOUT_AUTO) takes the volume: DVR on brickf32, the path-traced modes fall back to the
+    # reference textures because cellquad cannot index it
+    r.set_layout(3)
+    r.render(); assert np.array_equal(r.read_accum(), img)
+    r.settings.render_mode = "no_dda"
+    r.render(); assert np.isfinite(r.read_accum()).all()
     r.close()
 
 

@@ -49,7 +49,7 @@ VxParams = struct_from_header("volxel_hip.h", "VxParams")
 VxCounters = struct_from_header("volxel_hip.h", "VxCounters")
 
 MODE_DEFAULT, MODE_NO_DDA, MODE_RAYMARCH, MODE_DVR, MODE_DVR_PHONG = range(5)
-LAYOUT_REFERENCE, LAYOUT_CELLQUAD, LAYOUT_BRICKF32 = 0, 1, 2
+LAYOUT_REFERENCE, LAYOUT_CELLQUAD, LAYOUT_BRICKF32, LAYOUT_AUTO = 0, 1, 2, 3
 RENDER_MODES = {"default": MODE_DEFAULT, "no_dda": MODE_NO_DDA, "raymarch": MODE_RAYMARCH,
                 "dvr": MODE_DVR, "dvr_phong": MODE_DVR_PHONG}
 SHARD_TILE = 64
@@ -123,6 +123,7 @@ def load_library():
         "vx_debug_rng": ([vp, i32, vp, vp, u32, vp], i32),
         "vx_probe_gather_rate": ([vp, u32, P(C.c_double), P(u32)], i32),
         "vx_probe_gather_spread": ([vp, u32, P(u64)], i32),
+        "vx_probe_valu_rate": ([vp, P(C.c_double), P(u32)], i32),
         "vx_upload_stats": ([vp, P(C.c_double), P(u64), P(i32)], i32),
         "vx_debug_build_skip_mask": ([vp, P(u32), vp, u32, P(VxParams), vp, P(u32), P(u32)], i32),
         # preprocessor

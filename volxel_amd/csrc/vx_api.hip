@@ -42,7 +42,9 @@ struct VxContext {
   std::vector<void*> vol_allocs;
   void* cq_alloc = nullptr;
   void* bf_alloc = nullptr;
-  int layout = VX_LAYOUT_CELLQUAD;
+  int layout = VX_LAYOUT_AUTO;       // what the host asked for (vx_set_layout); eff_layout() is what a launch samples
+  bool auto_no_cq = false;           // AUTO: the volume is too large for the cellquad layout (path modes use REFERENCE)
+  bool auto_no_bf = false;           // AUTO: too large for brickf32 as well (everything uses REFERENCE)
 
   // transfer function
   float4* tf = nullptr;
@@ -384,13 +386,28 @@ static int ensure_counters(VxContext* c, size_t waves) {
   return VX_OK;
 }
 
+// The device layout the kernels of the current render mode sample.  VX_LAYOUT_AUTO (default): the DVR modes march
+// the brickf32 layout through LDS windows (vx_dvr_lds.hpp: fastest, 4 bytes per voxel), the path-traced reference
+// modes gather from cellquad (two 16-byte loads per trilinear look-up instead of eight bounds-checked taps).
+static int primary_layout(const VxContext* c) {
+  if (c->layout != VX_LAYOUT_AUTO) return c->layout;
+  return c->auto_no_bf ? VX_LAYOUT_REFERENCE : VX_LAYOUT_BRICKF32;
+}
+static int eff_layout(const VxContext* c) {
+  if (c->layout != VX_LAYOUT_AUTO) return c->layout;
+  const int m = c->has_params ? c->params.render_mode : VX_MODE_DVR;
+  if (m == VX_MODE_DVR || m == VX_MODE_DVR_PHONG) return primary_layout(c);
+  return c->auto_no_cq ? VX_LAYOUT_REFERENCE : VX_LAYOUT_CELLQUAD;
+}
+
 template <int MODE>
 static void launch_generic(VxContext* c, const MultiOut& mo, float weight, dim3 grid, size_t lds, hipStream_t stream) {
   grid.x *= mo.count ? mo.count : 1u;
-  if (c->layout == VX_LAYOUT_BRICKF32)
+  const int lay = eff_layout(c);
+  if (lay == VX_LAYOUT_BRICKF32)
     hipLaunchKernelGGL((render_generic<MODE, LAYOUT_BF>), grid, dim3(256), lds, stream, c->params,
                        c->dv, c->tf, c->tf_len, mo, weight, c->tm);
-  else if (c->layout == VX_LAYOUT_CELLQUAD)
+  else if (lay == VX_LAYOUT_CELLQUAD)
     hipLaunchKernelGGL((render_generic<MODE, LAYOUT_CQ>), grid, dim3(256), lds, stream, c->params,
                        c->dv, c->tf, c->tf_len, mo, weight, c->tm);
   else
@@ -402,10 +419,11 @@ static void launch_generic(VxContext* c, const MultiOut& mo, float weight, dim3 
 template <int MODE>
 static void launch_paths(VxContext* c, const MultiOut& mo, float weight, dim3 grid, size_t lds, hipStream_t stream) {
   grid.x *= mo.count ? mo.count : 1u;
-  if (c->layout == VX_LAYOUT_BRICKF32)
+  const int lay = eff_layout(c);
+  if (lay == VX_LAYOUT_BRICKF32)
     hipLaunchKernelGGL((render_paths<MODE, LAYOUT_BF>), grid, dim3(256), lds, stream, c->params, c->dv, c->tf, c->tf_len,
                        mo, weight, c->tm);
-  else if (c->layout == VX_LAYOUT_CELLQUAD)
+  else if (lay == VX_LAYOUT_CELLQUAD)
     hipLaunchKernelGGL((render_paths<MODE, LAYOUT_CQ>), grid, dim3(256), lds, stream, c->params, c->dv, c->tf, c->tf_len,
                        mo, weight, c->tm);
   else
@@ -527,7 +545,14 @@ static int alloc_layout(VxContext* c, uint32_t& n_layers) {
     c->dv.bf = nullptr;
   }
   n_layers = 0;
-  if (c->layout == VX_LAYOUT_BRICKF32) {
+  c->auto_no_cq = c->auto_no_bf = false;
+  if (c->layout == VX_LAYOUT_AUTO) {   // what the volume's size allows
+    const uint64_t nv = (uint64_t)c->dv.bc[0] * c->dv.bc[1] * c->dv.bc[2] * 512u;
+    const uint64_t nq = (uint64_t)(c->dv.bc[0] + 1) * (c->dv.bc[1] + 1) * (c->dv.bc[2] + 1) * CQ_BRICK_QUADS;
+    c->auto_no_bf = nv / 4u > 0xffffffffull;
+    c->auto_no_cq = nq > 0xffffffffull;
+  }
+  if (primary_layout(c) == VX_LAYOUT_BRICKF32) {
     uint64_t n_vox = (uint64_t)c->dv.bc[0] * c->dv.bc[1] * c->dv.bc[2] * 512u;
     // the staging loads index the layout in 16-byte units with 32 bits: 64 GiB, about 2500^3 voxels
     if (n_vox / 4u > 0xffffffffull)
@@ -538,7 +563,7 @@ static int alloc_layout(VxContext* c, uint32_t& n_layers) {
     n_layers = c->dv.bc[2];
     return VX_OK;
   }
-  if (c->layout != VX_LAYOUT_CELLQUAD) return VX_OK;
+  if (primary_layout(c) != VX_LAYOUT_CELLQUAD) return VX_OK;
   for (int i = 0; i < 3; ++i) c->dv.cq_bc[i] = c->dv.bc[i] + 1;
   uint64_t n_quads = (uint64_t)c->dv.cq_bc[0] * c->dv.cq_bc[1] * c->dv.cq_bc[2] * CQ_BRICK_QUADS;
   // the march indexes quads with 32 bits (and bricks with 24-bit multiplies): 64 GiB, about 1550^3 voxels
@@ -555,7 +580,7 @@ static int alloc_layout(VxContext* c, uint32_t& n_layers) {
 // fill z layers [z0, z1) of the layout on `st` (one thread per quad / voxel; layers are contiguous in both layouts)
 static int build_layout_layers(VxContext* c, uint32_t z0, uint32_t z1, hipStream_t st) {
   if (z1 <= z0) return VX_OK;
-  if (c->layout == VX_LAYOUT_BRICKF32) {
+  if (primary_layout(c) == VX_LAYOUT_BRICKF32) {
     const uint64_t per = (uint64_t)c->dv.bc[0] * c->dv.bc[1] * 512u;
     const uint64_t first = per * z0, end = per * z1;
     for (uint64_t at = first; at < end;) {   // <= 2^31 threads per launch
@@ -564,7 +589,7 @@ static int build_layout_layers(VxContext* c, uint32_t z0, uint32_t z1, hipStream
                          (float*)c->bf_alloc, at, at + n);
       at += n;
     }
-  } else if (c->layout == VX_LAYOUT_CELLQUAD) {
+  } else if (primary_layout(c) == VX_LAYOUT_CELLQUAD) {
     const uint64_t per = (uint64_t)c->dv.cq_bc[0] * c->dv.cq_bc[1] * CQ_BRICK_QUADS;
     const uint64_t first = per * z0, end = per * z1;
     for (uint64_t at = first; at < end;) {
@@ -590,6 +615,24 @@ static int ensure_brickf32(VxContext* c) {
     uint64_t n = n_vox - at < (1ull << 31) ? n_vox - at : (1ull << 31);
     hipLaunchKernelGGL(build_brickf32, dim3((uint32_t)((n + 255) / 256)), dim3(256), 0, c->stream, c->dv,
                        (float*)c->bf_alloc, at, at + n);
+    at += n;
+  }
+  VX_HIP(c, hipGetLastError());
+  return VX_OK;
+}
+
+// the cellquad layout built beside the primary one the first time a mode that gathers from it is rendered
+// (VX_LAYOUT_AUTO: the path-traced reference modes)
+static int ensure_cellquad(VxContext* c) {
+  if (c->dv.cq) return VX_OK;
+  for (int i = 0; i < 3; ++i) c->dv.cq_bc[i] = c->dv.bc[i] + 1;
+  const uint64_t n_quads = (uint64_t)c->dv.cq_bc[0] * c->dv.cq_bc[1] * c->dv.cq_bc[2] * CQ_BRICK_QUADS;
+  VX_HIP(c, hipMalloc(&c->cq_alloc, n_quads * sizeof(float4)));
+  c->dv.cq = (const float4*)c->cq_alloc;
+  for (uint64_t at = 0; at < n_quads;) {
+    uint64_t n = n_quads - at < (1ull << 31) ? n_quads - at : (1ull << 31);
+    hipLaunchKernelGGL(build_cellquad, dim3((uint32_t)((n + 255) / 256)), dim3(256), 0, c->stream, c->dv,
+                       (float4*)c->cq_alloc, at, at + n);
     at += n;
   }
   VX_HIP(c, hipGetLastError());
@@ -797,7 +840,8 @@ int vx_upload_brick_grid(VxContext* c, const VxBrickGrid* g) {
 int vx_set_layout(VxContext* c, int layout) {
   if (!c) return VX_ERR_INVALID;
   VX_DEV(c);
-  if (layout != VX_LAYOUT_REFERENCE && layout != VX_LAYOUT_CELLQUAD && layout != VX_LAYOUT_BRICKF32)
+  if (layout != VX_LAYOUT_REFERENCE && layout != VX_LAYOUT_CELLQUAD && layout != VX_LAYOUT_BRICKF32 &&
+      layout != VX_LAYOUT_AUTO)
     VX_FAIL(c, VX_ERR_INVALID, "vx_set_layout: unknown layout %d", layout);
   if (layout == c->layout) return VX_OK;
   c->layout = layout;
@@ -925,11 +969,11 @@ static bool tuned_possible(const VxContext* c) {
 // the LDS-window kernel (vx_dvr_lds.hpp): DVR on the brickf32 layout, Phong wherever brickf32 data is resident
 static bool use_lds_kernel(const VxContext* c) {
   if (!tuned_possible(c)) return false;
-  if (c->params.render_mode == VX_MODE_DVR) return c->layout == VX_LAYOUT_BRICKF32;
+  if (c->params.render_mode == VX_MODE_DVR) return eff_layout(c) == VX_LAYOUT_BRICKF32;
   return c->params.render_mode == VX_MODE_DVR_PHONG && c->dv.bf != nullptr;
 }
 static bool is_tuned(const VxContext* c) {
-  const bool dvr_cq = c->params.render_mode == VX_MODE_DVR && c->layout == VX_LAYOUT_CELLQUAD;
+  const bool dvr_cq = c->params.render_mode == VX_MODE_DVR && eff_layout(c) == VX_LAYOUT_CELLQUAD;
   return tuned_possible(c) && (dvr_cq || use_lds_kernel(c));
 }
 
@@ -960,8 +1004,14 @@ static int prepare_render(VxContext* c, dim3& grid) {
       }
     }
   }
-  if (c->params.render_mode == VX_MODE_DVR_PHONG && c->layout == VX_LAYOUT_CELLQUAD && tuned_possible(c)) {
-    int rc = ensure_brickf32(c);
+  {
+    // the layouts this launch samples, built on first use beside the one the upload built
+    const int lay = eff_layout(c);
+    int rc = VX_OK;
+    if (lay == VX_LAYOUT_CELLQUAD) rc = ensure_cellquad(c);
+    if (!rc && (lay == VX_LAYOUT_BRICKF32 ||
+                (c->params.render_mode == VX_MODE_DVR_PHONG && lay == VX_LAYOUT_CELLQUAD && tuned_possible(c))))
+      rc = ensure_brickf32(c);
     if (rc) return rc;
   }
   uint32_t groups = (c->tm.tiles_per_shard + 7u) / 8u;
@@ -1257,9 +1307,10 @@ int vx_probe_tile_costs(VxContext* c, uint32_t* costs, uint32_t n) {
   if (rc) return rc;
   uint32_t* d = nullptr;
   VX_HIP(c, hipMalloc(&d, (size_t)n * 4));
-  if (c->layout == VX_LAYOUT_BRICKF32)
+  const int lay = eff_layout(c);
+  if (lay == VX_LAYOUT_BRICKF32)
     hipLaunchKernelGGL((probe_tile_costs<LAYOUT_BF>), dim3(n), dim3(64), 0, c->stream, c->params, c->dv, c->tf, c->tf_len, c->tm, d);
-  else if (c->layout == VX_LAYOUT_CELLQUAD)
+  else if (lay == VX_LAYOUT_CELLQUAD)
     hipLaunchKernelGGL((probe_tile_costs<LAYOUT_CQ>), dim3(n), dim3(64), 0, c->stream, c->params, c->dv, c->tf, c->tf_len, c->tm, d);
   else
     hipLaunchKernelGGL((probe_tile_costs<LAYOUT_REF>), dim3(n), dim3(64), 0, c->stream, c->params, c->dv, c->tf, c->tf_len, c->tm, d);
@@ -1417,6 +1468,36 @@ int vx_debug_rng(VxContext* c, int op, const uint32_t* a, const uint32_t* b, uin
   return VX_OK;
 }
 
+// measurement hook: what the vector ALUs of this device sustain -- clocks (nominal) per wave64 VALU instruction per SIMD
+int vx_probe_valu_rate(VxContext* c, double* clk_out, uint32_t* clock_khz_out) {
+  if (!c || !clk_out) return VX_ERR_INVALID;
+  VX_DEV(c);
+  float* sink = nullptr;
+  hipEvent_t e0 = nullptr, e1 = nullptr;
+  hipError_t e = hipMalloc(&sink, 4);
+  if (e == hipSuccess) e = hipEventCreate(&e0);
+  if (e == hipSuccess) e = hipEventCreate(&e1);
+  const int cus = c->prop.multiProcessorCount, iters = 4096, blocks = cus * 8;   // 32 waves per CU = 8 per SIMD
+  float ms = 0.f;
+  for (int rep = 0; rep < 3 && e == hipSuccess; ++rep) {
+    e = hipEventRecord(e0, c->stream);
+    hipLaunchKernelGGL(probe_valu_rate, dim3(blocks), dim3(256), 0, c->stream, sink, iters, 1.0001f, 0.5f);
+    if (e == hipSuccess) e = hipGetLastError();
+    if (e == hipSuccess) e = hipEventRecord(e1, c->stream);
+    if (e == hipSuccess) e = hipEventSynchronize(e1);
+    if (e == hipSuccess) e = hipEventElapsedTime(&ms, e0, e1);
+  }
+  if (e0) (void)hipEventDestroy(e0);
+  if (e1) (void)hipEventDestroy(e1);
+  (void)hipFree(sink);
+  if (e != hipSuccess) VX_FAIL(c, VX_ERR_DEVICE, "vx_probe_valu_rate: %s", hipGetErrorString(e));
+  const double khz = (double)c->prop.clockRate;
+  const double inst_per_simd = (double)iters * 16.0 * 8.0;   // 8 waves per SIMD, 16 FMAs per iteration each
+  *clk_out = (ms * 1e-3 * khz * 1e3) / inst_per_simd;
+  if (clock_khz_out) *clock_khz_out = (uint32_t)c->prop.clockRate;
+  return VX_OK;
+}
+
 // measurement hook: L1 gather rate for a given number of distinct lines per gather instruction
 int vx_probe_gather_rate(VxContext* c, uint32_t lines, double* clk_out, uint32_t* clock_khz_out) {
   if (!c || !clk_out || lines < 1u || lines > 64u) return VX_ERR_INVALID;
@@ -1458,7 +1539,7 @@ int vx_probe_gather_spread(VxContext* c, uint32_t frame_index, uint64_t out3[3])
   dim3 grid;
   int rc = prepare_render(c, grid);
   if (rc) return rc;
-  if (!(is_tuned(c) && c->layout == VX_LAYOUT_CELLQUAD && c->params.render_mode == VX_MODE_DVR))
+  if (!(is_tuned(c) && eff_layout(c) == VX_LAYOUT_CELLQUAD && c->params.render_mode == VX_MODE_DVR))
     VX_FAIL(c, VX_ERR_INVALID, "vx_probe_gather_spread: needs render_mode dvr on the cellquad layout");
   const size_t waves = (size_t)grid.x * 4u;
   DevCounters* d = nullptr;

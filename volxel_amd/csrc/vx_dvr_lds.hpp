@@ -92,8 +92,16 @@ VXD float mix8(float v000, float v100, float v010, float v110, float v001, float
   return fma_(h, fz, l * wz);
 }
 
+// occupancy asked of the register allocator: the DVR build fits 58 VGPRs without a spill and gains from 8 resident
+// waves per SIMD (ms per frame at 5 / 6 / 7 / 8 waves: 0.434 / 0.431 / 0.420 / 0.415); the Phong build needs 86
+#ifndef VX_W_LDS
+#define VX_W_LDS 8
+#endif
+#ifndef VX_W_LDS_PHONG
+#define VX_W_LDS_PHONG 1
+#endif
 template <int S, bool PHONG, bool SKIP>
-__global__ __launch_bounds__(256) void render_dvr_lds(const VxParams p, const DevVolume v,
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(PHONG ? VX_W_LDS_PHONG : VX_W_LDS, 8))) void render_dvr_lds(const VxParams p, const DevVolume v,
                                                        const float4* __restrict__ tf_global, uint32_t tf_len,
                                                        const MultiOut mo, float weight, const TileMap tm,
                                                        const uint32_t* __restrict__ order) {
@@ -139,6 +147,7 @@ __global__ __launch_bounds__(256) void render_dvr_lds(const VxParams p, const De
   const float4* __restrict__ bf4 = reinterpret_cast<const float4*>(v.bf);   // 16-byte units: 64 GiB of layout in 32 bits
   const uint32_t sh = 3u + v.skip_level, md0 = v.skip_dims[0], md1 = v.skip_dims[1];
   const uint32_t cmaxx = ex + 7u, cmaxy = ey + 7u, cmaxz = ez + 7u;
+  const float inv_dt = SKIP ? 1.0f / r.dt : 0.0f;
   // Phong terms (vx_modes.hpp Frame::dvr<true>)
   V3 nl = v3(-p.light_dir[0], -p.light_dir[1], -p.light_dir[2]);
   V3 hv = v3(0.f, 0.f, 0.f);
@@ -162,95 +171,116 @@ __global__ __launch_bounds__(256) void render_dvr_lds(const VxParams p, const De
   };
   next_sample();
 
-  while (true) {
-    const unsigned long long live = __ballot(alive);
-    if (live == 0ull) break;
-    // ---- 1. anchor the window --------------------------------------------------------------------------
-    // the wave marches in the direction of its first live lane (rays of a wave are nearly parallel; any choice is
-    // correct, it only decides which end of the cell range the window hugs)
-    const int first = (int)__builtin_ctzll(live);
-    const bool fwx = __builtin_amdgcn_readlane(__builtin_bit_cast(int, r.idir.x), first) >= 0;   // sign bit clear
-    const bool fwy = __builtin_amdgcn_readlane(__builtin_bit_cast(int, r.idir.y), first) >= 0;
-    const bool fwz = __builtin_amdgcn_readlane(__builtin_bit_cast(int, r.idir.z), first) >= 0;
-    int LOx, LOy, LOz;
-    {
-      int mnx = wave_minmax<true>(alive ? cxi : 0x7fffffff), mxx = wave_minmax<false>(alive ? cxi : (int)0x80000000);
-      int mny = wave_minmax<true>(alive ? cyi : 0x7fffffff), mxy = wave_minmax<false>(alive ? cyi : (int)0x80000000);
-      int mnz = wave_minmax<true>(alive ? czi : 0x7fffffff), mxz = wave_minmax<false>(alive ? czi : (int)0x80000000);
-      // forward: start at the smallest cell; backward: end at the largest.  When the live cells fit the window
-      // with room to spare, centre the slack on the far side of the march (the side the rays move into).
-      LOx = fwx ? mnx - TL::LO_MARGIN : mxx + TL::HI_MARGIN - (DX - 1);
-      LOy = fwy ? mny - TL::LO_MARGIN : mxy + TL::HI_MARGIN - (DY - 1);
-      LOz = fwz ? mnz - TL::LO_MARGIN : mxz + TL::HI_MARGIN - (DZ - 1);
-      // x is staged in aligned 16-byte chunks: a forward window starts at or below its anchor cell (round down), a
-      // backward window ends at or above it (round up) -- the anchor stays inside, up to 3 columns are unused
-      LOx = fwx ? (LOx & ~3) : ((LOx + 3) & ~3);
+  // The wave marches in the direction of its first live lane (rays of a wave are nearly parallel and keep their
+  // direction; any choice is correct, it only decides which end of the cell range a window hugs).
+  bool fwx = true, fwy = true, fwz = true;
+  {
+    const unsigned long long live0 = __ballot(alive);
+    if (live0 != 0ull) {
+      const int first = (int)__builtin_ctzll(live0);
+      fwx = __builtin_amdgcn_readlane(__builtin_bit_cast(int, r.idir.x), first) >= 0;   // sign bit clear
+      fwy = __builtin_amdgcn_readlane(__builtin_bit_cast(int, r.idir.y), first) >= 0;
+      fwz = __builtin_amdgcn_readlane(__builtin_bit_cast(int, r.idir.z), first) >= 0;
     }
-    // a lane can step while its sample's cell, with the margins, is inside [LO, LO + D)
-    auto inside = [&](int cx, int cy, int cz) {
-      uint32_t rx = (uint32_t)(cx - LOx - TL::LO_MARGIN), ry = (uint32_t)(cy - LOy - TL::LO_MARGIN),
-               rz = (uint32_t)(cz - LOz - TL::LO_MARGIN);
-      return (rx < (uint32_t)(DX - TL::LO_MARGIN - TL::HI_MARGIN)) & (ry < (uint32_t)(DY - TL::LO_MARGIN - TL::HI_MARGIN)) &
-             (rz < (uint32_t)(DZ - TL::LO_MARGIN - TL::HI_MARGIN));
-    };
-    if (__ballot(alive & inside(cxi, cyi, czi)) == 0ull) {
-      // lanes too far apart for one window (a wave astride two entry faces of the clip box): serve the first lane
+  }
+  int LOx = 0, LOy = 0, LOz = 0;   // origin of the resident window (wave uniform)
+  // window origin from the extreme cell of the lanes in `mask` along each axis: a forward window starts at the
+  // smallest cell, a backward window ends at the largest; `slack` cells of extra room behind the anchor.
+  // x is staged in aligned 16-byte chunks: a forward window starts at or below its anchor cell (round down), a
+  // backward window ends at or above it (round up) -- the anchor stays inside, up to 3 columns are unused.
+  auto anchor = [&](bool mask, int cx, int cy, int cz, int slack, int& ox, int& oy, int& oz) {
+    const int ex_ = wave_minmax<true>(mask ? (fwx ? cx : -cx) : 0x7fffffff);   // min of c, or -(max of c)
+    const int ey_ = wave_minmax<true>(mask ? (fwy ? cy : -cy) : 0x7fffffff);
+    const int ez_ = wave_minmax<true>(mask ? (fwz ? cz : -cz) : 0x7fffffff);
+    ox = fwx ? ex_ - TL::LO_MARGIN - slack : -ex_ + TL::HI_MARGIN - (DX - 1) + slack;
+    oy = fwy ? ey_ - TL::LO_MARGIN - slack : -ey_ + TL::HI_MARGIN - (DY - 1) + slack;
+    oz = fwz ? ez_ - TL::LO_MARGIN - slack : -ez_ + TL::HI_MARGIN - (DZ - 1) + slack;
+    ox = fwx ? (ox & ~3) : ((ox + 3) & ~3);
+  };
+  // a lane can step while its sample's cell, with the margins, is inside [origin, origin + D)
+  auto inside_of = [&](int ox, int oy, int oz, int cx, int cy, int cz) {
+    uint32_t rx = (uint32_t)(cx - ox - TL::LO_MARGIN), ry = (uint32_t)(cy - oy - TL::LO_MARGIN),
+             rz = (uint32_t)(cz - oz - TL::LO_MARGIN);
+    return (rx < (uint32_t)(DX - TL::LO_MARGIN - TL::HI_MARGIN)) & (ry < (uint32_t)(DY - TL::LO_MARGIN - TL::HI_MARGIN)) &
+           (rz < (uint32_t)(DZ - TL::LO_MARGIN - TL::HI_MARGIN));
+  };
+  // exact window for the lanes as they stand; lanes too far apart for one window (a wave astride two entry faces of
+  // the clip box): serve the first live lane
+  auto exact_window = [&](unsigned long long live) {
+    anchor(alive, cxi, cyi, czi, 0, LOx, LOy, LOz);
+    if (__ballot(alive & inside_of(LOx, LOy, LOz, cxi, cyi, czi)) == 0ull) {
+      const int first = (int)__builtin_ctzll(live);
       LOx = __builtin_amdgcn_readlane(cxi, first) - TL::LO_MARGIN - (fwx ? 0 : DX - 1 - TL::LO_MARGIN - TL::HI_MARGIN);
       LOx = fwx ? (LOx & ~3) : ((LOx + 3) & ~3);
       LOy = __builtin_amdgcn_readlane(cyi, first) - TL::LO_MARGIN - (fwy ? 0 : DY - 1 - TL::LO_MARGIN - TL::HI_MARGIN);
       LOz = __builtin_amdgcn_readlane(czi, first) - TL::LO_MARGIN - (fwz ? 0 : DZ - 1 - TL::LO_MARGIN - TL::HI_MARGIN);
     }
-
-    // ---- 2. stage the window: lane = (y,z) row, four aligned 16-byte chunks --------------------------------
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");   // earlier tile reads are done
-    __builtin_amdgcn_wave_barrier();
-    {
-      // chunk c covers x = LOx + 4c .. +3: brick column and offset inside the brick row are wave uniform
-      constexpr int NC = DX / 4;
-      uint32_t xoff[NC];
-      bool xin[NC];
+  };
+  // stage, part 1: lane = (y,z) row of the window at (ox,oy,oz): X / 4 aligned 16-byte loads into registers, issued
+  // back to back; rows and chunks outside the volume are zeros (A4)
+  constexpr int NC = DX / 4;
+  auto issue_loads = [&](int ox, int oy, int oz, float4 (&vals)[TL::PASSES][NC]) {
+    uint32_t xoff[NC];
+    bool xin[NC];
+#pragma unroll
+    for (int c = 0; c < NC; ++c) {   // chunk c covers x = ox + 4c .. +3: brick column and half row are wave uniform
+      const int gx = ox + 4 * c;
+      xin[c] = (uint32_t)gx < ex;
+      xoff[c] = (((uint32_t)gx >> 3) << 7) + (((uint32_t)gx & 7u) >> 2);   // brick x * 128 + half row (16-byte units)
+    }
+#pragma unroll
+    for (int ps = 0; ps < TL::PASSES; ++ps) {
+      const uint32_t row = lane + 64u * (uint32_t)ps;
+      const uint32_t zz = row / (uint32_t)DY, yy = row - zz * (uint32_t)DY;
+      const int gy = oy + (int)yy, gz = oz + (int)zz;
+      const bool rin = row < (uint32_t)TL::ROWS && (uint32_t)gy < ey && (uint32_t)gz < ez;
+      // 16-byte units from the start of the layout to the brick row (y,z) of brick column 0
+      const uint32_t rowbase = ((((uint32_t)gz >> 3) * bcy + ((uint32_t)gy >> 3)) * bcx << 7) +
+                               ((((uint32_t)gz & 7u) << 4) | (((uint32_t)gy & 7u) << 1));
 #pragma unroll
       for (int c = 0; c < NC; ++c) {
-        const int gx = LOx + 4 * c;
-        xin[c] = (uint32_t)gx < ex;
-        xoff[c] = (((uint32_t)gx >> 3) << 7) + (((uint32_t)gx & 7u) >> 2);   // brick x * 128 + half row (16-byte units)
+        float4 val = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (rin && xin[c]) val = bf4[rowbase + xoff[c]];
+        vals[ps][c] = val;
       }
-      float4 vals[TL::PASSES][NC];
+    }
+    n_loads += (uint32_t)NC * (uint32_t)TL::PASSES;
+  };
+  // stage, part 2: the rows into the wave's tile
+  auto write_tile = [&](float4 (&vals)[TL::PASSES][NC]) {
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");   // earlier tile reads are done
+    __builtin_amdgcn_wave_barrier();
 #pragma unroll
-      for (int ps = 0; ps < TL::PASSES; ++ps) {
-        const uint32_t row = lane + 64u * (uint32_t)ps;
+    for (int ps = 0; ps < TL::PASSES; ++ps) {
+      const uint32_t row = lane + 64u * (uint32_t)ps;
+      if (row < (uint32_t)TL::ROWS) {
         const uint32_t zz = row / (uint32_t)DY, yy = row - zz * (uint32_t)DY;
-        const int gy = LOy + (int)yy, gz = LOz + (int)zz;
-        const bool rin = row < (uint32_t)TL::ROWS && (uint32_t)gy < ey && (uint32_t)gz < ez;
-        // 16-byte units from the start of the layout to the brick row (y,z) of brick column 0
-        const uint32_t rowbase = ((((uint32_t)gz >> 3) * bcy + ((uint32_t)gy >> 3)) * bcx << 7) +
-                                 ((((uint32_t)gz & 7u) << 4) | (((uint32_t)gy & 7u) << 1));
+        float4* dst = reinterpret_cast<float4*>(tile + zz * (uint32_t)SS + yy * (uint32_t)RS);
 #pragma unroll
-        for (int c = 0; c < NC; ++c) {
-          float4 val = make_float4(0.f, 0.f, 0.f, 0.f);
-#ifndef VX_LDS_EXP_NOLOAD   // timing experiment only: no global loads
-          if (rin && xin[c]) val = bf4[rowbase + xoff[c]];
-#else
-          if (rin && xin[c]) val.x = (float)(rowbase + xoff[c]);
-#endif
-          vals[ps][c] = val;
-        }
+        for (int c = 0; c < NC; ++c) dst[c] = vals[ps][c];
       }
-#pragma unroll
-      for (int ps = 0; ps < TL::PASSES; ++ps) {
-        const uint32_t row = lane + 64u * (uint32_t)ps;
-        if (row < (uint32_t)TL::ROWS) {
-          const uint32_t zz = row / (uint32_t)DY, yy = row - zz * (uint32_t)DY;
-          float4* dst = reinterpret_cast<float4*>(tile + zz * (uint32_t)SS + yy * (uint32_t)RS);
-#pragma unroll
-          for (int c = 0; c < NC; ++c) dst[c] = vals[ps][c];
-        }
-      }
-      n_loads += (uint32_t)NC * (uint32_t)TL::PASSES;
     }
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     __builtin_amdgcn_wave_barrier();
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+  };
+
+  // (Tried: issuing the loads of the NEXT window -- predicted from where every lane leaves the resident one -- before
+  // the march, into registers, so that their latency hides behind it.  With an exact-enough guess the windows and
+  // lane slots stayed the same, yet the frame took 0.452 instead of 0.437 ms: the 5-6 resident waves per SIMD already
+  // cover the staging latency, the guess and its wasted loads only added instructions.  Not kept.)
+  {
+    const unsigned long long live = __ballot(alive);
+    if (live != 0ull) {
+      exact_window(live);
+      float4 vals[TL::PASSES][NC];
+      issue_loads(LOx, LOy, LOz, vals);
+      write_tile(vals);
+    }
+  }
+  while (true) {
+    if (__ballot(alive) == 0ull) break;
+    auto inside = [&](int cx, int cy, int cz) { return inside_of(LOx, LOy, LOz, cx, cy, cz); };
 
     // ---- 3. march: up to S steps out of LDS -------------------------------------------------------------------
 #pragma unroll 1
@@ -259,13 +289,30 @@ __global__ __launch_bounds__(256) void render_dvr_lds(const VxParams p, const De
       const unsigned long long gm = __ballot(go);
       if (gm == 0ull) break;                      // nobody can step in this window any more: restage
       bool eval = go;
+      float jump = 0.0f;   // SKIP: further steps this lane may pass over (all inside the same empty macro cell)
       if (SKIP) {
         uint32_t cx = (uint32_t)(cxi + 1), cy = (uint32_t)(cyi + 1), cz = (uint32_t)(czi + 1);
         cx = cx < cmaxx ? cx : cmaxx; cy = cy < cmaxy ? cy : cmaxy; cz = cz < cmaxz ? cz : cmaxz;
         uint32_t mi = ((cz >> sh) * md1 + (cy >> sh)) * md0 + (cx >> sh);
         bool empty = (mask_lds[mi >> 5] >> (mi & 31u)) & 1u;
         eval = go & !empty;
-        n_skipped += (uint32_t)__builtin_popcountll(__ballot(go & empty));
+        const bool emp = go & empty;
+        const unsigned long long em = __ballot(emp);
+        n_skipped += (uint32_t)__builtin_popcountll(em);
+        if (em != 0ull) {   // wave uniform
+          // distance (in t) from this sample to the faces of its macro cell, along the ray: the lane moves on to two
+          // steps short of the exit face (vx_dvr.hpp does the same with the last sample of a batch); every sample
+          // passed over lies inside the same empty macro cell, so the set of evaluated samples is unchanged
+          const float Sf = (float)(1u << sh);
+          const float bx = (float)((cx >> sh) << sh) - 1.0f, by = (float)((cy >> sh) << sh) - 1.0f,
+                      bz = (float)((cz >> sh) << sh) - 1.0f;   // q in [b, b + S) inside the macro cell
+          const float dx = r.idir.x > 0.0f ? (bx + Sf - qx) / r.idir.x : (r.idir.x < 0.0f ? (bx - qx) / r.idir.x : 3.0e38f);
+          const float dy = r.idir.y > 0.0f ? (by + Sf - qy) / r.idir.y : (r.idir.y < 0.0f ? (by - qy) / r.idir.y : 3.0e38f);
+          const float dz = r.idir.z > 0.0f ? (bz + Sf - qz) / r.idir.z : (r.idir.z < 0.0f ? (bz - qz) / r.idir.z : 3.0e38f);
+          float n = floorf(fminf(dx, fminf(dy, dz)) * inv_dt) - 2.0f;   // stay >= one whole step short of the exit face
+          n = fminf(n, 1048576.0f);
+          jump = (emp && n >= 1.0f) ? n : 0.0f;
+        }
       }
       {
         unsigned long long m = __ballot(eval);
@@ -278,14 +325,8 @@ __global__ __launch_bounds__(256) void render_dvr_lds(const VxParams p, const De
       off = go ? off : (TL::LO_MARGIN * (SS + RS + 1));
       const float* tp = tile + off;
       const float* tq = tp + SS;                  // slice z + 1
-#ifdef VX_LDS_EXP_NOREAD   // timing experiment only: one tap read instead of four
-      const float v000 = tp[0], v100 = tp[1], v010 = v000 * 0.5f, v110 = v100 * 0.5f;
-      const float v001 = v000 * 0.25f, v101 = v100 * 0.25f, v011 = v000 * 0.75f, v111 = v100 * 0.75f;
-      (void)tq;
-#else
       const float v000 = tp[0], v100 = tp[1], v010 = tp[RS], v110 = tp[RS + 1];
       const float v001 = tq[0], v101 = tq[1], v011 = tq[RS], v111 = tq[RS + 1];
-#endif
       n_reads += 4u;
       const float fx = qx - flx, fy = qy - fly, fz = qz - flz;
       const float wx = 1.0f - fx, wy = 1.0f - fy, wz = 1.0f - fz;
@@ -345,9 +386,16 @@ __global__ __launch_bounds__(256) void render_dvr_lds(const VxParams p, const De
       T = contrib ? (done ? 0.0f : Tn) : T;
       far = done ? -__builtin_inff() : far;
       // the lanes that stepped move on to their next sample
-      kf = go ? kf + 1.0f : kf;
+      kf = go ? kf + 1.0f + jump : kf;
       next_sample();
     }
+    // ---- next window ------------------------------------------------------------------------------------------------
+    const unsigned long long live = __ballot(alive);
+    if (live == 0ull) break;
+    exact_window(live);
+    float4 vals[TL::PASSES][NC];
+    issue_loads(LOx, LOy, LOz, vals);
+    write_tile(vals);
   }
 
   if (in_image) dvr_store(p, v, r, Cx, Cy, Cz, T, weight, slab, si);

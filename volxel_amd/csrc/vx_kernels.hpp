@@ -411,6 +411,20 @@ __global__ __launch_bounds__(256) void debug_rng(int op, const uint32_t* __restr
   }
 }
 
+// measurement hook (vx_probe_valu_rate): nothing but independent v_fma_f32 chains, 8 waves per SIMD
+__global__ __launch_bounds__(256) void probe_valu_rate(float* __restrict__ out, int iters, float a, float b) {
+  float acc[16];
+#pragma unroll
+  for (int i = 0; i < 16; ++i) acc[i] = (float)threadIdx.x + (float)i;
+  for (int it = 0; it < iters; ++it)
+#pragma unroll
+    for (int i = 0; i < 16; ++i) acc[i] = __builtin_fmaf(acc[i], a, b);
+  float r = 0.f;
+#pragma unroll
+  for (int i = 0; i < 16; ++i) r += acc[i];
+  if (r == 12345.678f) out[0] = r;
+}
+
 // measurement hook (vx_probe_gather_rate): nothing but 16-byte-per-lane gathers whose 64 lane addresses fall
 // into `lines` distinct 128-byte lines of a 16 KiB (L1-resident) table; 8 gathers in flight per wave
 __device__ inline uint32_t probe_hash(uint32_t x) {

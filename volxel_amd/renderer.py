@@ -471,6 +471,12 @@ class Volxel3DRenderer:
         self._check(self._lib.vx_probe_gather_rate(self._ctx, int(lines), C.byref(clk), C.byref(khz)))
         return clk.value, khz.value
 
+    def probe_valu_rate(self):
+        """clocks (nominal) per wave64 VALU instruction per SIMD this device sustains, and the nominal clock in kHz"""
+        clk, khz = C.c_double(), C.c_uint32()
+        self._check(self._lib.vx_probe_valu_rate(self._ctx, C.byref(clk), C.byref(khz)))
+        return clk.value, khz.value
+
     def probe_gather_spread(self, frame_index: int = 0):
         """(q0 gather instructions, wave-wide distinct lines, quad line look-ups) of one DVR frame"""
         out = (C.c_uint64 * 3)()
