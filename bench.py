@@ -216,8 +216,9 @@ def main():
                          "VX_LAYOUT_AUTO, which marches DVR on brickf32")
     ap.add_argument("--gather-every", type=int, default=64,
                     help="N>1: all_gather the framebuffer once per this many accumulation frames")
-    ap.add_argument("--frames-per-launch", type=int, default=DEFAULT_FRAMES_PER_LAUNCH,
-                    help="independent accumulation frames rendered by one kernel launch (1..64)")
+    ap.add_argument("--frames-per-launch", type=int, default=None,
+                    help="independent accumulation frames rendered by one kernel launch (1..64); default 16 x the "
+                         "number of ranks (a launch then carries the same work per GPU whatever N), at most 64")
     ap.add_argument("--no-jitter", action="store_true",
                     help="diagnostic: pixel-centre rays, identical in every frame (NOT the reference's behaviour)")
     ap.add_argument("--no-skip-variant", action="store_true", help="do not run the secondary measurement with skipping")
@@ -276,7 +277,7 @@ def main():
         gathered = torch.empty(world * slab.numel(), dtype=torch.float32, device="cuda")
         image = torch.empty(a.height * a.width * 4, dtype=torch.float32, device="cuda")
 
-    P = max(1, min(64, a.frames_per_launch))
+    P = max(1, min(64, a.frames_per_launch if a.frames_per_launch else DEFAULT_FRAMES_PER_LAUNCH * world))
 
     def batch(f0, n, per_launch):
         """n accumulation frames f0.. (n <= per_launch): one launch, then -- at display cadence -- the gather"""
