@@ -10,13 +10,19 @@ export type BrickGridMessage = {            // WasmWorkerMessageDicomReturn, com
 };
 export declare const VolxelRenderMode: { default: 0; no_dda: 1; raymarch: 2; dvr: 3; dvr_phong: 4 };
 export declare function generateTransferFunction(colors: ColorStop[], generatedSteps?: number): { data: Float32Array; length: number };
-export declare class Camera { pos: number[]; view: number[]; constructor(distance?: number); viewMatrix(): number[]; projMatrix(aspect: number, fov?: number): number[]; }
+export declare class Camera {
+  pos: number[]; view: number[];
+  /** [build] null: the reference's perspective camera (scene.ts:65-72); a number: orthographic, image spans +-orthoHalfHeight world units vertically */
+  orthoHalfHeight: number | null;
+  constructor(distance?: number); viewMatrix(): number[]; projMatrix(aspect: number, fov?: number): number[];
+}
 export declare class Environment {          // representation/environment.ts; row 0 of `floats` = top
   constructor(floats: Float32Array, width: number, height: number, strength?: number);
   floats: Float32Array; width: number; height: number; strength: number;
   static default(): Environment;
 }
 export declare class Volxel3DDicomRenderer {
+  /** layout: 0 reference textures, 1 cellquad, 2 brickf32, 3 (default) per render mode -- include/volxel_hip.h VxLayout */
   constructor(opts?: { width?: number; height?: number; device?: number; layout?: number; lowResPreview?: boolean });
   environment: Environment | null;
   setEnvironment(env: Environment | null): void;
@@ -41,7 +47,8 @@ export declare class Volxel3DDicomRenderer {
   finish(): void;
   readAccum(): Float32Array;
   readDisplay(): Uint8Array;
-  counters(): { samples: number; rays: number; pixels: number; skipSteps: number; gradSamples: number; laneSlots: number; launches: number; kernelMs: number; lastKernelMs: number };
+  counters(): { samples: number; rays: number; pixels: number; skipSteps: number; gradSamples: number; laneSlots: number; launches: number; frames: number;
+                kernelMs: number; lastKernelMs: number; gathers: number; ldsReads: number; mergeMs: number; minLaunchFrames: number; maxLaunchFrames: number };
   resetCounters(): void;
   dispose(): void;
 }
