@@ -144,8 +144,9 @@ def l1_block(r, c, clock_khz_hint=None):
     name, cus, mem = r.device_info()
     lpg, qpg = lines / n, quads / n
     look = max(16, min(64, int(round(qpg))))
-    floor_clk, khz = r.probe_gather_rate(look)
-    ideal_clk, _ = r.probe_gather_rate(16)       # every group of 4 lanes inside one line: the best a gather can do
+    dist = max(1, min(look, int(round(lpg))))
+    floor_clk, khz = r.probe_gather_rate(look, dist)   # the march's look-ups per gather over its distinct lines
+    ideal_clk, _ = r.probe_gather_rate(16, min(16, dist))   # every group of 4 lanes inside one line: the best a gather can do
     clk = (c.kernel_ms * 1e-3) * (khz * 1e3) * cus / c.gathers
     return {"bound": "l1", "unit": "clk per gather instruction per CU at the nominal clock",
             "nominal_clock_mhz": round(khz / 1e3, 1),
@@ -153,11 +154,14 @@ def l1_block(r, c, clock_khz_hint=None):
             "bytes_returned_per_gather": 1024,
             "lines_per_gather": round(lpg, 2), "quad_lookups_per_gather": round(qpg, 2),
             "clk_per_gather_per_cu": round(clk, 2), "floor_clk": round(floor_clk, 2),
-            "frac": round(floor_clk / clk, 4),
+            # probe and kernel each run at the clock the chip chooses for them: a few per cent either way is DVFS
+            # noise, so the fraction saturates at 1 (frac_raw keeps the quotient as measured)
+            "frac": round(min(1.0, floor_clk / clk), 4), "frac_raw": round(floor_clk / clk, 4),
             "floor_clk_if_coalesced": round(ideal_clk, 2), "frac_of_coalesced": round(ideal_clk / clk, 4),
             "l1_return_gbs": round(c.gathers * 1024 / (c.kernel_ms * 1e-3) / 1e9, 1),
-            "note": "floor_clk = vx_probe_gather_rate(round(quad_lookups_per_gather)): global_load_dwordx4 only, "
-                    "L1-resident, same number of line look-ups per instruction; frac = floor / measured (<= 1, falls "
+            "note": "floor_clk = vx_probe_gather_rate(round(quad_lookups_per_gather), round(lines_per_gather)): "
+                    "global_load_dwordx4 only, L1-resident, same number of line look-ups per instruction over the same number "
+                    "of distinct lines; frac = floor / measured (<= 1, falls "
                     "when the kernel adds stalls); frac_of_coalesced = what a march whose 4-lane groups never "
                     "straddle a line would reach"}
 

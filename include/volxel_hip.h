@@ -288,11 +288,14 @@ const char* vx_version(void);
 int vx_debug_rng(VxContext* ctx, int op, const uint32_t* a, const uint32_t* b, uint32_t n, uint32_t* out);
 
 /* measurement hook (no reference counterpart): what the vector L1 of this device sustains for the
- * gather shape of the DVR march -- wave instructions of 16 bytes per lane whose 64 lane addresses
- * fall into `lines` distinct L1-resident 128-byte lines (1..64), nothing else in the loop, 20 waves
- * per CU, 8 gathers in flight per wave.  Returns the cost in clocks per gather instruction per CU at
- * the device's nominal clock (clock_khz_out).  bench.py calls it for the roofline.l1 block. */
-int vx_probe_gather_rate(VxContext* ctx, uint32_t lines, double* clk_per_gather_out, uint32_t* clock_khz_out);
+ * gather shape of the cellquad DVR march -- wave instructions of 16 bytes per lane whose 64 lanes form `lines`
+ * groups of consecutive lanes, each group inside one L1-resident 128-byte line, the groups using `distinct`
+ * (<= lines) different lines in turn; nothing else in the loop, 20 waves per CU, 8 gathers in flight per wave.
+ * Returns the cost in clocks per gather instruction per CU at the device's nominal clock (clock_khz_out).
+ * bench.py calls it for the roofline.l1 block with lines = the march's line look-ups per gather over its
+ * 4-lane groups and distinct = its distinct lines per gather over the whole wave. */
+int vx_probe_gather_rate(VxContext* ctx, uint32_t lines, uint32_t distinct, double* clk_per_gather_out,
+                         uint32_t* clock_khz_out);
 /* measurement hook: what the vector ALUs of this device sustain: clocks (nominal clock) per wave64 VALU instruction per
  * SIMD, from independent v_fma_f32 chains at 8 waves per SIMD.  bench.py prices the instruction count of the LDS-window
  * DVR kernel with it (roofline.issue). */

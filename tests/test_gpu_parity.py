@@ -722,7 +722,9 @@ def test_counters_report_the_launches_that_ran(oracle):
     clk, khz = r.probe_gather_rate(16)
     clk1, _ = r.probe_gather_rate(1)
     clk64, _ = r.probe_gather_rate(64)
-    assert khz >= 1000000 and 10.0 < clk1 <= clk < clk64 < 400.0
+    clk30_10, _ = r.probe_gather_rate(30, 10)     # 30 line look-ups over 10 distinct lines, the shape of the march
+    clk30, _ = r.probe_gather_rate(30)
+    assert khz >= 1000000 and 10.0 < clk1 <= clk < clk64 < 400.0 and clk <= clk30_10 <= clk30 * 1.05
     r.close()
     # the default layout (VX_LAYOUT_AUTO) marches DVR through LDS windows: staging loads and LDS tap reads are counted
     r = Volxel3DRenderer(192, 128)

@@ -121,7 +121,7 @@ def load_library():
         "vx_version": ([], C.c_char_p),
         "vx_debug_unorm_table": ([vp, vp], i32),
         "vx_debug_rng": ([vp, i32, vp, vp, u32, vp], i32),
-        "vx_probe_gather_rate": ([vp, u32, P(C.c_double), P(u32)], i32),
+        "vx_probe_gather_rate": ([vp, u32, u32, P(C.c_double), P(u32)], i32),
         "vx_probe_gather_spread": ([vp, u32, P(u64)], i32),
         "vx_probe_valu_rate": ([vp, P(C.c_double), P(u32)], i32),
         "vx_upload_stats": ([vp, P(C.c_double), P(u64), P(i32)], i32),

@@ -1499,8 +1499,8 @@ int vx_probe_valu_rate(VxContext* c, double* clk_out, uint32_t* clock_khz_out) {
 }
 
 // measurement hook: L1 gather rate for a given number of distinct lines per gather instruction
-int vx_probe_gather_rate(VxContext* c, uint32_t lines, double* clk_out, uint32_t* clock_khz_out) {
-  if (!c || !clk_out || lines < 1u || lines > 64u) return VX_ERR_INVALID;
+int vx_probe_gather_rate(VxContext* c, uint32_t lines, uint32_t distinct, double* clk_out, uint32_t* clock_khz_out) {
+  if (!c || !clk_out || lines < 1u || lines > 64u || distinct < 1u || distinct > lines) return VX_ERR_INVALID;
   VX_DEV(c);
   float4* table = nullptr;
   float* sink = nullptr;
@@ -1514,7 +1514,7 @@ int vx_probe_gather_rate(VxContext* c, uint32_t lines, double* clk_out, uint32_t
   float ms = 0.f;
   for (int rep = 0; rep < 3 && e == hipSuccess; ++rep) {   // the last repetition is the one reported
     e = hipEventRecord(e0, c->stream);
-    hipLaunchKernelGGL(probe_gather_rate, dim3(blocks), dim3(256), 0, c->stream, table, lines, iters, sink);
+    hipLaunchKernelGGL(probe_gather_rate, dim3(blocks), dim3(256), 0, c->stream, table, lines, distinct, iters, sink);
     if (e == hipSuccess) e = hipGetLastError();
     if (e == hipSuccess) e = hipEventRecord(e1, c->stream);
     if (e == hipSuccess) e = hipEventSynchronize(e1);

@@ -92,8 +92,8 @@ __global__ __launch_bounds__(256) void render_dvr_cq(const VxParams p, const Dev
   // launch slot -> (frame slot, logical block); blocks in longest-first order of the previous frame
   // launch index = bslot*count + fslot.  (An XCD-class-preserving interleave was measured slower
   // at 2 and 4 shards: one frame slot per XCD class balances better than one tile set per class.)
-  const uint32_t fslot = mo.count > 1 ? blockIdx.x % mo.count : 0u;
-  const uint32_t bslot = mo.count > 1 ? blockIdx.x / mo.count : blockIdx.x;
+  uint32_t fslot, bslot;
+  multi_slot(blockIdx.x, mo.count, fslot, bslot);
   const uint32_t blk = order ? order[bslot] : bslot;
   float4* __restrict__ slab = mo.out[fslot];
   DevCounters* __restrict__ dc = mo.dc[fslot];

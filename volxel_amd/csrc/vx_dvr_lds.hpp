@@ -115,8 +115,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(PHONG ? VX_
   if (SKIP)
     for (uint32_t i = threadIdx.x; i < v.skip_words; i += blockDim.x) mask_lds[i] = v.skip_bits[i];
   __syncthreads();
-  const uint32_t fslot = mo.count > 1 ? blockIdx.x % mo.count : 0u;
-  const uint32_t bslot = mo.count > 1 ? blockIdx.x / mo.count : blockIdx.x;
+  uint32_t fslot, bslot;
+  multi_slot(blockIdx.x, mo.count, fslot, bslot);
   const uint32_t blk = order ? order[bslot] : bslot;
   float4* __restrict__ slab = mo.out[fslot];
   DevCounters* __restrict__ dc = mo.dc[fslot];

@@ -111,6 +111,23 @@ struct MultiOut {
   uint32_t count;
 };
 
+// launch slot p of a multi-frame launch -> (frame slot, block slot).  Default: frame slots of one block are consecutive
+// launch slots (p % count).  -DVX_SLOT_XCD: launch slots are dealt to the 8 XCDs round-robin (p % 8 names the XCD
+// class), so let the slots of one class walk the blocks of that class with all their frame slots back to back -- the
+// tiles of a class then stay on one XCD's L2 across frames, as block_to_tile arranges for a single frame.  Measured on
+// config 3 (ms per frame at 8 / 16 / 24 frames per launch): default 0.437 / 0.410 / 0.393, VX_SLOT_XCD 0.432 / 0.413 / 0.405.
+VXD void multi_slot(uint32_t p, uint32_t count, uint32_t& fslot, uint32_t& bslot) {
+  if (count <= 1u) { fslot = 0u; bslot = p; return; }
+#ifdef VX_SLOT_XCD
+  const uint32_t x = p & 7u, i = p >> 3;
+  fslot = i % count;
+  bslot = (i / count) * 8u + x;
+#else
+  fslot = p % count;
+  bslot = p / count;
+#endif
+}
+
 // Occupancy the register allocator is asked for, per mode.  The path-traced modes are bound by latency and
 // divergence (about 37 % of the lane slots of an issued VALU instruction do work), so more resident waves
 // pay even at the price of a few spills: measured on config 3 (tools/variant_modes.sh, ms per frame, 32 frames
@@ -148,8 +165,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(generic_min
   } else {
     tf.lut = tf_global;
   }
-  const uint32_t fslot = mo.count > 1 ? blockIdx.x % mo.count : 0u;
-  const uint32_t blk = mo.count > 1 ? blockIdx.x / mo.count : blockIdx.x;
+  uint32_t fslot, blk;
+  multi_slot(blockIdx.x, mo.count, fslot, blk);
   float4* __restrict__ slab = mo.out[fslot];
   DevCounters* __restrict__ dc = mo.dc[fslot];
   const uint32_t frame = mo.frame[fslot];
@@ -425,14 +442,16 @@ __global__ __launch_bounds__(256) void probe_valu_rate(float* __restrict__ out, 
   if (r == 12345.678f) out[0] = r;
 }
 
-// measurement hook (vx_probe_gather_rate): nothing but 16-byte-per-lane gathers whose 64 lane addresses fall
-// into `lines` distinct 128-byte lines of a 16 KiB (L1-resident) table; 8 gathers in flight per wave
+// measurement hook (vx_probe_gather_rate): nothing but 16-byte-per-lane gathers.  The 64 lanes form `lines` groups of
+// consecutive lanes, every group inside one 128-byte line of a 16 KiB (L1-resident) table; the groups use `distinct`
+// different lines in turn (distinct == lines: every group its own line; distinct < lines: a line is looked up by
+// several groups, as in the march, where neighbouring 4-lane groups straddle the same lines).  8 gathers in flight.
 __device__ inline uint32_t probe_hash(uint32_t x) {
   x ^= x >> 16; x *= 0x7feb352du; x ^= x >> 15; x *= 0x846ca68bu; x ^= x >> 16;
   return x;
 }
-__global__ __launch_bounds__(256) void probe_gather_rate(const float4* __restrict__ base, uint32_t lines, int iters,
-                                                          float* __restrict__ out) {
+__global__ __launch_bounds__(256) void probe_gather_rate(const float4* __restrict__ base, uint32_t lines, uint32_t distinct,
+                                                          int iters, float* __restrict__ out) {
   const uint32_t lane = threadIdx.x & 63u, wave = blockIdx.x * 4u + (threadIdx.x >> 6);
   const uint32_t g = (lane * lines) >> 6;                      // group of lanes sharing one line
   const uint32_t first = (g * 64u + lines - 1u) / lines;       // first lane of the group
@@ -444,7 +463,7 @@ __global__ __launch_bounds__(256) void probe_gather_rate(const float4* __restric
 #pragma unroll
     for (int u = 0; u < 8; ++u) {
       s = s * 1664525u + 1013904223u;                           // wave-uniform stream
-      uint32_t line = ((s >> 8) + g * 37u) & 127u;              // distinct per group: 37 is odd
+      uint32_t line = ((s >> 8) + (g % distinct) * 37u) & 127u; // 37 is odd: `distinct` different lines per gather
       q[u] = base[(line << 3) + within];
     }
 #pragma unroll

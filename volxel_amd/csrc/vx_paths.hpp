@@ -48,8 +48,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(VX_W_PATHS,
     tf.lut = tf_global;
   }
   __syncthreads();
-  const uint32_t fslot = mo.count > 1 ? blockIdx.x % mo.count : 0u;
-  const uint32_t blk = mo.count > 1 ? blockIdx.x / mo.count : blockIdx.x;
+  uint32_t fslot, blk;
+  multi_slot(blockIdx.x, mo.count, fslot, blk);
   float4* __restrict__ slab = mo.out[fslot];
   DevCounters* __restrict__ dc = mo.dc[fslot];
   const uint32_t frame = mo.frame[fslot];

@@ -464,11 +464,13 @@ class Volxel3DRenderer:
         self._check(self._lib.vx_upload_stats(self._ctx, C.byref(s), C.byref(b), C.byref(pin)))
         return s.value, b.value, bool(pin.value)
 
-    def probe_gather_rate(self, lines: int):
-        """clocks per 16-byte-per-lane gather instruction per CU (nominal clock) when the 64 lane addresses
-        fall into `lines` L1-resident lines, and the nominal clock in kHz"""
+    def probe_gather_rate(self, lines: int, distinct: int | None = None):
+        """clocks per 16-byte-per-lane gather instruction per CU (nominal clock) when the 64 lanes form `lines` groups of
+        consecutive lanes, each inside one L1-resident line, using `distinct` (default: lines) different lines; and the
+        nominal clock in kHz"""
         clk, khz = C.c_double(), C.c_uint32()
-        self._check(self._lib.vx_probe_gather_rate(self._ctx, int(lines), C.byref(clk), C.byref(khz)))
+        d = int(lines) if distinct is None else int(distinct)
+        self._check(self._lib.vx_probe_gather_rate(self._ctx, int(lines), d, C.byref(clk), C.byref(khz)))
         return clk.value, khz.value
 
     def probe_valu_rate(self):
