@@ -364,6 +364,9 @@ def main():
         roof = {
             "bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
             "frac": round(achieved / HBM_PEAK_GBS, 4),
+            "frac_note": ("above 1: the byte model of SURVEY 8(d) charges every sample its own 16 bytes; the kernel stages each "
+                          "voxel once per window and neighbouring samples share taps, so the HBM pins carry far less (traffic / "
+                          "hbm_measured) -- the limiter is the one in roofline.issue / roofline.l1") if achieved > HBM_PEAK_GBS else None,
             **prof,
             "kernel": KERNEL[a.layout],
             "avg_kernel_ms": round(c.kernel_ms / launches, 4), "launches": int(c.launches), "frames": int(c.frames),
@@ -373,6 +376,10 @@ def main():
                                  + ("(the result this kernel writes; the blend's 32 B/pixel/frame are in `blend`)"
                                     if multi else "(accumulator read + write in the same kernel)"),
             "rank0_gsamples_per_s_kernel_only": round(c.samples / (c.kernel_ms / 1e3) / 1e9, 3) if c.kernel_ms else None,
+            "hbm_measured": ({"gbs": round(prof["traffic"] / avg_kernel_s / 1e9, 1),
+                              "frac": round(prof["traffic"] / avg_kernel_s / 1e9 / HBM_PEAK_GBS, 4),
+                              "note": "rocprofv3 bytes of the profiled run of this command / this run's kernel time"}
+                             if prof.get("traffic") and avg_kernel_s > 0 else None),
             "blend": {"kernel": "vx::merge_results", "ms_per_launch": round(c.merge_ms / launches, 4),
                       "algorithmic_bytes_per_launch": int(c.pixels / launches * (BYTES_PER_PIXEL_RESULT + BYTES_PER_PIXEL_BLEND / max(fpl, 1))),
                       "note": "reads the per-frame results, applies fragment.frag:158 in frame order, one accumulator "

@@ -336,55 +336,61 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(PHONG ? VX_
       const float ml = fma_(lx1, fy, lx0 * wy), mh = fma_(hx1, fy, hx0 * wy);
       const float d = scale * fma_(mh, fz, ml * wz);
       const float dn = d * inv_maj;
-      const int ti = med3_i32((int)(dn * lenf), 0, last);   // dn >= 0: truncation == floor
-      const bool in_range = !(dn < sr0 || dn > sr1);
-      float4 rgba = tf_lds[ti];
-      const float alpha = (eval && in_range) ? rgba.w : 0.0f;
-      const bool contrib = alpha > 0.0f;
-      if (PHONG) {
-        const unsigned long long cm = __ballot(contrib);
-        if (cm != 0ull) {   // wave-uniform: the 24 further taps only when some lane shades
-          n_grads += (uint32_t)__builtin_popcountll(cm);
-          n_reads += 12u;
-          if (contrib) {
-            // central differences one voxel either side, in the sample's cell frame (cells c +- e, the sample's
-            // fractions): T(c + e) - T(c - e) per axis, each T a full common.glsl:62-68 mix times the density scale
-            // x: T(c + ex) mixes the taps x+1, x+2 and T(c - ex) the taps x-1, x of the same four rows -- no lerp is shared
-            const float xm0 = tp[-1], xp0 = tp[2], xm1 = tp[RS - 1], xp1 = tp[RS + 2];
-            const float xm2 = tq[-1], xp2 = tq[2], xm3 = tq[RS - 1], xp3 = tq[RS + 2];
-            const float gx = scale * mix8(v100, xp0, v110, xp1, v101, xp2, v111, xp3, fx, wx, fy, wy, fz, wz) -
-                             scale * mix8(xm0, v000, xm1, v010, xm2, v001, xm3, v011, fx, wx, fy, wy, fz, wz);
-            // y: T(c + ey) mixes rows y+1, y+2 -- the x lerp of row y+1 is the centre's lx1 / hx1 (same operands, same
-            // operation: same bits); likewise T(c - ey) reuses lx0 / hx0
-            const float ym0 = tp[-RS], ym1 = tp[-RS + 1], yp0 = tp[2 * RS], yp1 = tp[2 * RS + 1];
-            const float ym2 = tq[-RS], ym3 = tq[-RS + 1], yp2 = tq[2 * RS], yp3 = tq[2 * RS + 1];
-            const float lxp = fma_(yp1, fx, yp0 * wx), hxp = fma_(yp3, fx, yp2 * wx);
-            const float lxm = fma_(ym1, fx, ym0 * wx), hxm = fma_(ym3, fx, ym2 * wx);
-            const float gy = scale * fma_(fma_(hxp, fy, hx1 * wy), fz, fma_(lxp, fy, lx1 * wy) * wz) -
-                             scale * fma_(fma_(hx0, fy, hxm * wy), fz, fma_(lx0, fy, lxm * wy) * wz);
-            // z: T(c + ez) mixes slices z+1, z+2 -- the y lerp of slice z+1 is the centre's mh; T(c - ez) reuses ml
-            const float* tzm = tp - SS;
-            const float* tzp = tq + SS;
-            const float zm0 = tzm[0], zm1 = tzm[1], zm2 = tzm[RS], zm3 = tzm[RS + 1];
-            const float zp0 = tzp[0], zp1 = tzp[1], zp2 = tzp[RS], zp3 = tzp[RS + 1];
-            const float mp = fma_(fma_(zp3, fx, zp2 * wx), fy, fma_(zp1, fx, zp0 * wx) * wy);
-            const float mm = fma_(fma_(zm3, fx, zm2 * wx), fy, fma_(zm1, fx, zm0 * wx) * wy);
-            const float gz = scale * fma_(mp, fz, mh * wz) - scale * fma_(ml, fz, mm * wz);
-            const V3 g = v3(gx * gsx, gy * gsy, gz * gsz);
-            phong_shade(p, g, nl, hv, rgba);
+      // A7 / A12 only where they can matter: a sample outside the sample range, or whose TF entry has alpha 0, leaves
+      // tau, T and C exactly as they are (fma(0, dt, tau) == tau, a colour increment of 0), and on this kind of data most
+      // wave steps have no lane inside the range at all (config 3: 82 %), so the LUT fetch, the classification and
+      // the composite sit behind one wave-uniform branch -- 22 of the 85 vector instructions of a step
+      const bool in_range = eval & !(dn < sr0 || dn > sr1);
+      if (__ballot(in_range) != 0ull) {
+        const int ti = med3_i32((int)(dn * lenf), 0, last);   // dn >= 0: truncation == floor
+        float4 rgba = tf_lds[ti];
+        const float alpha = in_range ? rgba.w : 0.0f;
+        const bool contrib = alpha > 0.0f;
+        if (PHONG) {
+          const unsigned long long cm = __ballot(contrib);
+          if (cm != 0ull) {   // wave-uniform: the 24 further taps only when some lane shades
+            n_grads += (uint32_t)__builtin_popcountll(cm);
+            n_reads += 12u;
+            if (contrib) {
+              // central differences one voxel either side, in the sample's cell frame (cells c +- e, the sample's
+              // fractions): T(c + e) - T(c - e) per axis, each T a full common.glsl:62-68 mix times the density scale
+              // x: T(c + ex) mixes the taps x+1, x+2 and T(c - ex) the taps x-1, x of the same four rows -- no lerp is shared
+              const float xm0 = tp[-1], xp0 = tp[2], xm1 = tp[RS - 1], xp1 = tp[RS + 2];
+              const float xm2 = tq[-1], xp2 = tq[2], xm3 = tq[RS - 1], xp3 = tq[RS + 2];
+              const float gx = scale * mix8(v100, xp0, v110, xp1, v101, xp2, v111, xp3, fx, wx, fy, wy, fz, wz) -
+                               scale * mix8(xm0, v000, xm1, v010, xm2, v001, xm3, v011, fx, wx, fy, wy, fz, wz);
+              // y: T(c + ey) mixes rows y+1, y+2 -- the x lerp of row y+1 is the centre's lx1 / hx1 (same operands, same
+              // operation: same bits); likewise T(c - ey) reuses lx0 / hx0
+              const float ym0 = tp[-RS], ym1 = tp[-RS + 1], yp0 = tp[2 * RS], yp1 = tp[2 * RS + 1];
+              const float ym2 = tq[-RS], ym3 = tq[-RS + 1], yp2 = tq[2 * RS], yp3 = tq[2 * RS + 1];
+              const float lxp = fma_(yp1, fx, yp0 * wx), hxp = fma_(yp3, fx, yp2 * wx);
+              const float lxm = fma_(ym1, fx, ym0 * wx), hxm = fma_(ym3, fx, ym2 * wx);
+              const float gy = scale * fma_(fma_(hxp, fy, hx1 * wy), fz, fma_(lxp, fy, lx1 * wy) * wz) -
+                               scale * fma_(fma_(hx0, fy, hxm * wy), fz, fma_(lx0, fy, lxm * wy) * wz);
+              // z: T(c + ez) mixes slices z+1, z+2 -- the y lerp of slice z+1 is the centre's mh; T(c - ez) reuses ml
+              const float* tzm = tp - SS;
+              const float* tzp = tq + SS;
+              const float zm0 = tzm[0], zm1 = tzm[1], zm2 = tzm[RS], zm3 = tzm[RS + 1];
+              const float zp0 = tzp[0], zp1 = tzp[1], zp2 = tzp[RS], zp3 = tzp[RS + 1];
+              const float mp = fma_(fma_(zp3, fx, zp2 * wx), fy, fma_(zp1, fx, zp0 * wx) * wy);
+              const float mm = fma_(fma_(zm3, fx, zm2 * wx), fy, fma_(zm1, fx, zm0 * wx) * wy);
+              const float gz = scale * fma_(mp, fz, mh * wz) - scale * fma_(ml, fz, mm * wz);
+              const V3 g = v3(gx * gsx, gy * gsy, gz * gsz);
+              phong_shade(p, g, nl, hv, rgba);
+            }
           }
         }
+        // tau += a*maj*dt; C += (T_prev - T) * rgb   (raymarch.glsl:43 / SURVEY A12) -- straight line, as vx_dvr.hpp
+        tau = fma_(alpha * maj, r.dt, tau);
+        const float Tn = __builtin_amdgcn_exp2f(tau * -1.4426950408889634f);
+        const float dT = contrib ? T - Tn : 0.0f;
+        Cx = fma_(dT, rgba.x, Cx);
+        Cy = fma_(dT, rgba.y, Cy);
+        Cz = fma_(dT, rgba.z, Cz);
+        const bool done = contrib && (tau >= ert);
+        T = contrib ? (done ? 0.0f : Tn) : T;
+        far = done ? -__builtin_inff() : far;
       }
-      // tau += a*maj*dt; C += (T_prev - T) * rgb   (raymarch.glsl:43 / SURVEY A12) -- straight line, as vx_dvr.hpp
-      tau = fma_(alpha * maj, r.dt, tau);
-      const float Tn = __builtin_amdgcn_exp2f(tau * -1.4426950408889634f);
-      const float dT = contrib ? T - Tn : 0.0f;
-      Cx = fma_(dT, rgba.x, Cx);
-      Cy = fma_(dT, rgba.y, Cy);
-      Cz = fma_(dT, rgba.z, Cz);
-      const bool done = contrib && (tau >= ert);
-      T = contrib ? (done ? 0.0f : Tn) : T;
-      far = done ? -__builtin_inff() : far;
       // the lanes that stepped move on to their next sample
       kf = go ? kf + 1.0f + jump : kf;
       next_sample();
