@@ -92,6 +92,10 @@ VXD int f2i(float x) {
   return r;
 }
 
+// lane mask of a per-lane condition (HIP's __ballot takes an int: the bool is first materialised as 0 / 1 and compared
+// again, two vector instructions per use)
+VXD unsigned long long ballot(bool b) { return __builtin_amdgcn_ballot_w64(b); }
+
 // a*b + c on 24-bit unsigned operands: one full-rate v_mad_u32_u24 (hipcc otherwise picks the
 // quarter-rate v_mad_u64_u32 for 32-bit index arithmetic)
 VXD uint32_t mad24(uint32_t a, uint32_t b, uint32_t c) {
@@ -103,6 +107,12 @@ VXD uint32_t mad24(uint32_t a, uint32_t b, uint32_t c) {
 VXD uint32_t mad24_s(uint32_t a, uint32_t b_uniform, uint32_t c) {
   uint32_t r;
   asm("v_mad_u32_u24 %0, %1, %2, %3" : "=v"(r) : "v"(a), "s"(b_uniform), "v"(c));
+  return r;
+}
+// clamp to [0, hi_uniform] in one instruction, the wave-uniform bound straight from its SGPR
+VXD int clamp0_i32(int x, int hi_uniform) {
+  int r;
+  asm("v_med3_i32 %0, %1, 0, %2" : "=v"(r) : "v"(x), "s"(hi_uniform));
   return r;
 }
 // clamp to [lo, hi] in one instruction

@@ -130,13 +130,16 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(PHONG ? VX_
 
   DvrRay r{};
   if (in_image) r = dvr_setup(p, px, py, frame);
-  bool alive = in_image && r.hit;
-  const uint32_t n_rays = (uint32_t)__builtin_popcountll(__ballot(alive));
+  const bool hit0 = in_image && r.hit;
+  const uint32_t n_rays = (uint32_t)__builtin_popcountll(ballot(hit0));
   // a lane is live while its next sample lies before `far`; a lane that misses, leaves the image or terminates
   // gets far = -inf, so liveness is recomputed from registers each step instead of being carried as a flag
-  float far = alive ? r.far : -__builtin_inff();
+  float far = hit0 ? r.far : -__builtin_inff();
 
-  const float scale = p.volume_density_scale, inv_maj = p.volume_inv_maj, maj = p.volume_maj;
+  float scale = p.volume_density_scale;
+  asm volatile("" : "+v"(scale));   // keep it in a VGPR: out of SGPRs the allocator re-loaded it from the kernel
+                                    // arguments inside the march loop, a scalar-memory wait per step
+  const float inv_maj = p.volume_inv_maj, maj = p.volume_maj;
   const float sr0 = p.sample_range[0], sr1 = p.sample_range[1];
   const float lenf = (float)tf_len;
   const int last = (int)tf_len - 1;
@@ -160,9 +163,11 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(PHONG ? VX_
   // cell of the lane's next sample
   float t = 0.f, qx = 0.f, qy = 0.f, qz = 0.f, flx = 0.f, fly = 0.f, flz = 0.f;
   int cxi = 0, cyi = 0, czi = 0;
+  // liveness is a function of registers (t, far, kf), evaluated where it is needed: a flag carried around the march
+  // loop costs a VGPR and four instructions per step to convert between flag and lane mask
+  auto is_alive = [&]() { return (t < far) & (kf < max_steps_f); };
   auto next_sample = [&]() {
     t = fma_(kf, r.dt, r.t0);
-    alive = (t < far) & (kf < max_steps_f);
     qx = fma_(t, r.idir.x, r.ipos.x) - 0.5f;
     qy = fma_(t, r.idir.y, r.ipos.y) - 0.5f;
     qz = fma_(t, r.idir.z, r.ipos.z) - 0.5f;
@@ -175,7 +180,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(PHONG ? VX_
   // direction; any choice is correct, it only decides which end of the cell range a window hugs).
   bool fwx = true, fwy = true, fwz = true;
   {
-    const unsigned long long live0 = __ballot(alive);
+    const unsigned long long live0 = ballot(is_alive());
     if (live0 != 0ull) {
       const int first = (int)__builtin_ctzll(live0);
       fwx = __builtin_amdgcn_readlane(__builtin_bit_cast(int, r.idir.x), first) >= 0;   // sign bit clear
@@ -207,8 +212,9 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(PHONG ? VX_
   // exact window for the lanes as they stand; lanes too far apart for one window (a wave astride two entry faces of
   // the clip box): serve the first live lane
   auto exact_window = [&](unsigned long long live) {
+    const bool alive = is_alive();
     anchor(alive, cxi, cyi, czi, 0, LOx, LOy, LOz);
-    if (__ballot(alive & inside_of(LOx, LOy, LOz, cxi, cyi, czi)) == 0ull) {
+    if (ballot(alive & inside_of(LOx, LOy, LOz, cxi, cyi, czi)) == 0ull) {
       const int first = (int)__builtin_ctzll(live);
       LOx = __builtin_amdgcn_readlane(cxi, first) - TL::LO_MARGIN - (fwx ? 0 : DX - 1 - TL::LO_MARGIN - TL::HI_MARGIN);
       LOx = fwx ? (LOx & ~3) : ((LOx + 3) & ~3);
@@ -270,7 +276,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(PHONG ? VX_
   // lane slots stayed the same, yet the frame took 0.452 instead of 0.437 ms: the 5-6 resident waves per SIMD already
   // cover the staging latency, the guess and its wasted loads only added instructions.  Not kept.)
   {
-    const unsigned long long live = __ballot(alive);
+    const unsigned long long live = ballot(is_alive());
     if (live != 0ull) {
       exact_window(live);
       float4 vals[TL::PASSES][NC];
@@ -279,14 +285,14 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(PHONG ? VX_
     }
   }
   while (true) {
-    if (__ballot(alive) == 0ull) break;
+    if (ballot(is_alive()) == 0ull) break;
     auto inside = [&](int cx, int cy, int cz) { return inside_of(LOx, LOy, LOz, cx, cy, cz); };
 
     // ---- 3. march: up to S steps out of LDS -------------------------------------------------------------------
 #pragma unroll 1
     for (int s = 0; s < S; ++s) {
-      const bool go = alive & inside(cxi, cyi, czi);
-      const unsigned long long gm = __ballot(go);
+      const bool go = is_alive() & inside(cxi, cyi, czi);
+      const unsigned long long gm = ballot(go);
       if (gm == 0ull) break;                      // nobody can step in this window any more: restage
       bool eval = go;
       float jump = 0.0f;   // SKIP: further steps this lane may pass over (all inside the same empty macro cell)
@@ -297,7 +303,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(PHONG ? VX_
         bool empty = (mask_lds[mi >> 5] >> (mi & 31u)) & 1u;
         eval = go & !empty;
         const bool emp = go & empty;
-        const unsigned long long em = __ballot(emp);
+        const unsigned long long em = ballot(emp);
         n_skipped += (uint32_t)__builtin_popcountll(em);
         if (em != 0ull) {   // wave uniform
           // distance (in t) from this sample to the faces of its macro cell, along the ray: the lane moves on to two
@@ -315,7 +321,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(PHONG ? VX_
         }
       }
       {
-        unsigned long long m = __ballot(eval);
+        unsigned long long m = ballot(eval);
         n_samples += (uint32_t)__builtin_popcountll(m);
         n_slots += 64u;
       }
@@ -341,13 +347,13 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(PHONG ? VX_
       // wave steps have no lane inside the range at all (config 3: 82 %), so the LUT fetch, the classification and
       // the composite sit behind one wave-uniform branch -- 22 of the 85 vector instructions of a step
       const bool in_range = eval & !(dn < sr0 || dn > sr1);
-      if (__ballot(in_range) != 0ull) {
-        const int ti = med3_i32((int)(dn * lenf), 0, last);   // dn >= 0: truncation == floor
+      if (ballot(in_range) != 0ull) {
+        const int ti = clamp0_i32((int)(dn * lenf), last);   // dn >= 0: truncation == floor
         float4 rgba = tf_lds[ti];
         const float alpha = in_range ? rgba.w : 0.0f;
         const bool contrib = alpha > 0.0f;
         if (PHONG) {
-          const unsigned long long cm = __ballot(contrib);
+          const unsigned long long cm = ballot(contrib);
           if (cm != 0ull) {   // wave-uniform: the 24 further taps only when some lane shades
             n_grads += (uint32_t)__builtin_popcountll(cm);
             n_reads += 12u;
@@ -396,7 +402,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(PHONG ? VX_
       next_sample();
     }
     // ---- next window ------------------------------------------------------------------------------------------------
-    const unsigned long long live = __ballot(alive);
+    const unsigned long long live = ballot(is_alive());
     if (live == 0ull) break;
     exact_window(live);
     float4 vals[TL::PASSES][NC];
@@ -405,7 +411,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(PHONG ? VX_
   }
 
   if (in_image) dvr_store(p, v, r, Cx, Cy, Cz, T, weight, slab, si);
-  const uint32_t n_px = (uint32_t)__builtin_popcountll(__ballot(in_image));
+  const uint32_t n_px = (uint32_t)__builtin_popcountll(ballot(in_image));
   add_counts(dc, n_samples, n_rays, n_px, n_skipped, n_grads, n_slots, blk, n_loads, n_reads);
 }
 
