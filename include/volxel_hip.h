@@ -116,7 +116,8 @@ typedef struct VxParams {
   int32_t dvr_jitter;    /* 1: sub-pixel + start jitter from the RNG like the reference
                             (fragment.frag:146, raymarch.glsl:30); 0: pixel centre,
                             start offset 0.5 step                                        */
-  int32_t dvr_max_steps;
+  int32_t dvr_max_steps; /* samples per ray at most, 0 .. 2^24 (the step index is an fp32 value:
+                            t_k = fma(k, dt, t0)); vx_set_params refuses more            */
   int32_t dvr_skip_empty; /* 1: exact empty-space skipping -- samples whose macro cell (16..64
                              voxels) can only see TF-transparent bricks are
                              not evaluated (their alpha is exactly 0) and not counted          */

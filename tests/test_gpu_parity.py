@@ -665,6 +665,18 @@ def test_error_contract():
         r.resize(0, 10)
     with pytest.raises(VolxelError):
         r.change_transfer_func(np.zeros(7, dtype=np.float32), 2)
+    # the DVR kernels count steps in fp32: a step limit past 2^24 could never be reached (and a zero step never ends)
+    from volxel_amd import read_u16_stack_to_grid, synth
+    r.setup_from_grid(read_u16_stack_to_grid(*synth.sphere(32)))
+    r.settings.render_mode = "dvr"
+    for field, bad in (("dvr_max_steps", (1 << 24) + 1), ("dvr_max_steps", -1), ("dvr_step_voxels", 0.0),
+                       ("dvr_step_voxels", float("nan"))):
+        good = getattr(r.settings, field)
+        setattr(r.settings, field, bad)
+        with pytest.raises(VolxelError, match=field):
+            r.bind_uniforms()
+        setattr(r.settings, field, good)
+    r.bind_uniforms()
 
 
 def test_host_rejects_arrays_shorter_than_their_size_fields(oracle):

@@ -22,5 +22,7 @@ for name, (vox, sp), clip in (("config2 CT phantom 256^3", synth.ct_phantom(256)
         c = r.counters()
         print(json.dumps(dict(case=name, skip=skip, ms_per_frame=round(c.kernel_ms / c.frames, 4),
                               Msamples=round(c.samples / c.frames / 1e6, 1), Mskipped=round(c.skip_steps / c.frames / 1e6, 1),
-                              lane_util=round(c.samples / max(c.lane_slots, 1), 3))), flush=True)
+                              lane_util=round(c.samples / max(c.lane_slots, 1), 3),
+                              Mwave_steps=round(c.lane_slots / 64 / c.frames / 1e6, 3),
+                              Mwindows=round(c.gathers / 3 / c.frames / 1e6, 3))), flush=True)
     r.close()

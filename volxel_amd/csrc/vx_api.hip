@@ -936,6 +936,10 @@ int vx_set_params(VxContext* c, const VxParams* p) {
   if ((p->render_mode == VX_MODE_DVR || p->render_mode == VX_MODE_DVR_PHONG) &&
       !(p->dvr_step_voxels > 0.0f))
     VX_FAIL(c, VX_ERR_INVALID, "vx_set_params: dvr_step_voxels must be > 0");
+  // the kernels count steps in fp32 (t_k = fma(k, dt, t0)): beyond 2^24 the count stops advancing
+  if ((p->render_mode == VX_MODE_DVR || p->render_mode == VX_MODE_DVR_PHONG) &&
+      (p->dvr_max_steps < 0 || p->dvr_max_steps > (1 << 24)))
+    VX_FAIL(c, VX_ERR_INVALID, "vx_set_params: dvr_max_steps %d outside [0, 2^24]", p->dvr_max_steps);
   bool reshard = !c->has_params || p->shard_count != c->params.shard_count ||
                  p->shard_rank != c->params.shard_rank;
   if (!c->has_params || memcmp(&c->params, p, sizeof(VxParams)) != 0) c->order_builds_left = 2;

@@ -20,6 +20,8 @@
 //      and termination are bit-identical to Frame<>::dvr and to the oracle.
 // No barriers: the tile is private to the wave.
 #pragma once
+#include <type_traits>
+
 #include "vx_dvr.hpp"
 
 namespace vx {
@@ -97,11 +99,15 @@ VXD float mix8(float v000, float v100, float v010, float v110, float v001, float
 #ifndef VX_W_LDS
 #define VX_W_LDS 8
 #endif
+// with the 8 KB macro-cell mask beside the tiles six workgroups fit a CU: 6 waves per SIMD, 80 VGPRs
+#ifndef VX_W_LDS_SKIP
+#define VX_W_LDS_SKIP 6
+#endif
 #ifndef VX_W_LDS_PHONG
 #define VX_W_LDS_PHONG 1
 #endif
 template <int S, bool PHONG, bool SKIP>
-__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(PHONG ? VX_W_LDS_PHONG : VX_W_LDS, 8))) void render_dvr_lds(const VxParams p, const DevVolume v,
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(PHONG ? VX_W_LDS_PHONG : (SKIP ? VX_W_LDS_SKIP : VX_W_LDS), 8))) void render_dvr_lds(const VxParams p, const DevVolume v,
                                                        const float4* __restrict__ tf_global, uint32_t tf_len,
                                                        const MultiOut mo, float weight, const TileMap tm,
                                                        const uint32_t* __restrict__ order) {
@@ -150,7 +156,9 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(PHONG ? VX_
   const float4* __restrict__ bf4 = reinterpret_cast<const float4*>(v.bf);   // 16-byte units: 64 GiB of layout in 32 bits
   const uint32_t sh = 3u + v.skip_level, md0 = v.skip_dims[0], md1 = v.skip_dims[1];
   const uint32_t cmaxx = ex + 7u, cmaxy = ey + 7u, cmaxz = ez + 7u;
-  const float inv_dt = SKIP ? 1.0f / r.dt : 0.0f;
+  // jumps over empty macro cells are sized in steps: only with steps well above the rounding of a sample position
+  // (2^-14 voxel at coordinate 1024); finer marches skip sample by sample
+  const float inv_dt = (SKIP && p.dvr_step_voxels >= 0.015625f) ? 1.0f / r.dt : 0.0f;
   // Phong terms (vx_modes.hpp Frame::dvr<true>)
   V3 nl = v3(-p.light_dir[0], -p.light_dir[1], -p.light_dir[2]);
   V3 hv = v3(0.f, 0.f, 0.f);
@@ -271,6 +279,83 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(PHONG ? VX_
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
   };
 
+  // ---- SKIP: exact empty-space skipping (A12 note: a sample in a macro cell that can only see TF-transparent bricks
+  // has alpha == 0 exactly) -------------------------------------------------------------------------------------------
+  // is the lane's next sample in an empty macro cell?  (defined for every lane: the clamps keep the index in the mask)
+  auto in_empty_cell = [&]() {
+    uint32_t cx = (uint32_t)(cxi + 1), cy = (uint32_t)(cyi + 1), cz = (uint32_t)(czi + 1);
+    cx = cx < cmaxx ? cx : cmaxx; cy = cy < cmaxy ? cy : cmaxy; cz = cz < cmaxz ? cz : cmaxz;
+    const uint32_t mi = mad24(mad24(cz >> sh, md1, cy >> sh), md0, cx >> sh);   // at most 65536 macro cells
+    return (bool)((mask_lds[mi >> 5] >> (mi & 31u)) & 1u);
+  };
+  // further steps a lane in an empty macro cell may pass over: it moves on to about one step short of the exit face of
+  // the cell (vx_dvr.hpp does the same with the last sample of a batch); every sample passed over lies inside the same
+  // empty macro cell, so the set of evaluated samples is unchanged
+  // (reciprocals of the direction once per ray; a jump only has to be conservative: the error of the three products
+  // is below a quarter step for the longest jump taken, one whole step is kept in hand.  A zero component gets a
+  // huge negative factor: its distance to the lower face (<= 0) becomes huge and drops out of the minimum.)
+  const float jix = !SKIP ? 0.f : (r.idir.x != 0.0f ? 1.0f / r.idir.x : -3.0e38f);
+  const float jiy = !SKIP ? 0.f : (r.idir.y != 0.0f ? 1.0f / r.idir.y : -3.0e38f);
+  const float jiz = !SKIP ? 0.f : (r.idir.z != 0.0f ? 1.0f / r.idir.z : -3.0e38f);
+  auto jump_of = [&](bool emp) {
+    const float Sf1 = (float)(1u << sh) - 1.0f;
+    uint32_t cx = (uint32_t)(cxi + 1), cy = (uint32_t)(cyi + 1), cz = (uint32_t)(czi + 1);
+    cx = cx < cmaxx ? cx : cmaxx; cy = cy < cmaxy ? cy : cmaxy; cz = cz < cmaxz ? cz : cmaxz;
+    // q in [b - 1, b - 1 + S) inside the macro cell at b = (c >> sh) << sh; exit face along the ray
+    const float ex = (float)((cx >> sh) << sh) + (r.idir.x > 0.0f ? Sf1 : -1.0f);
+    const float ey = (float)((cy >> sh) << sh) + (r.idir.y > 0.0f ? Sf1 : -1.0f);
+    const float ez = (float)((cz >> sh) << sh) + (r.idir.z > 0.0f ? Sf1 : -1.0f);
+    const float dmin = fminf((ex - qx) * jix, fminf((ey - qy) * jiy, (ez - qz) * jiz));
+    // samples k+1 .. k+n are passed over unseen: n < (steps to the exit face) keeps them inside the cell -- one whole
+    // step in hand against the rounding of dmin (< 1/4 step, above); the sample the lane lands on is tested like any
+    float n = floorf(dmin * inv_dt) - 1.0f;
+    n = fminf(n, 1048576.0f);
+    return (emp && n >= 1.0f) ? n : 0.0f;
+  };
+  // free flight: a sample in an empty macro cell needs no taps, hence no window -- before a window is placed the lanes
+  // that stand in empty cells pass over them (jump, then step by step to the exit face) while the others wait, so
+  // that windows are only staged where something can be seen.  Bounded: a lane still in empty space after FLY rounds
+  // goes on inside the next window (the march tests the mask per step wherever the window touches an empty cell).
+  constexpr int FLY = 48;
+  auto free_flight = [&]() {
+#pragma unroll 1
+    for (int it = 0; it < FLY; ++it) {
+      const bool emp = is_alive() & in_empty_cell();
+      const unsigned long long em = ballot(emp);
+      if (em == 0ull) break;
+      n_skipped += (uint32_t)__builtin_popcountll(em);
+      n_slots += 64u;
+      kf = emp ? kf + 1.0f + jump_of(emp) : kf;
+      next_sample();
+    }
+  };
+  // does the resident window touch an empty macro cell?  It is at most 12 cells wide and a macro cell at least 16, so
+  // the eight corner cells name every macro cell under it (lanes 0..7 test one each, with the clamps of the per-step test)
+  auto touches_empty = [&]() {
+    const int ax = (lane & 1u) ? LOx + DX - 1 : LOx, ay = (lane & 2u) ? LOy + DY - 1 : LOy,
+              az = (lane & 4u) ? LOz + DZ - 1 : LOz;
+    auto clampi = [](int x, uint32_t hi) { return (uint32_t)(x < 0 ? 0 : (x > (int)hi ? (int)hi : x)); };
+    const uint32_t cx = clampi(ax + 1, cmaxx), cy = clampi(ay + 1, cmaxy), cz = clampi(az + 1, cmaxz);
+    const uint32_t mi = mad24(mad24(cz >> sh, md1, cy >> sh), md0, cx >> sh);
+    const bool empty = (mask_lds[mi >> 5] >> (mi & 31u)) & 1u;
+    return (ballot(empty) & 0xffull) != 0ull;
+  };
+  bool wtest = false;   // SKIP: the resident window touches an empty macro cell: the march tests the mask per step
+  // place and stage the next window for the lanes in `live`; false: free flight ended every ray
+  auto next_window = [&](unsigned long long live) {
+    if (SKIP) {
+      free_flight();
+      live = ballot(is_alive());
+      if (live == 0ull) return false;
+    }
+    exact_window(live);
+    if (SKIP) wtest = touches_empty();
+    float4 vals[TL::PASSES][NC];
+    issue_loads(LOx, LOy, LOz, vals);
+    write_tile(vals);
+    return true;
+  };
+
   // (Tried: issuing the loads of the NEXT window -- predicted from where every lane leaves the resident one -- before
   // the march, into registers, so that their latency hides behind it.  With an exact-enough guess the windows and
   // lane slots stayed the same, yet the frame took 0.452 instead of 0.437 ms: the 5-6 resident waves per SIMD already
@@ -278,17 +363,14 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(PHONG ? VX_
   {
     const unsigned long long live = ballot(is_alive());
     if (live != 0ull) {
-      exact_window(live);
-      float4 vals[TL::PASSES][NC];
-      issue_loads(LOx, LOy, LOz, vals);
-      write_tile(vals);
+      (void)next_window(live);
     }
   }
-  while (true) {
-    if (ballot(is_alive()) == 0ull) break;
-    auto inside = [&](int cx, int cy, int cz) { return inside_of(LOx, LOy, LOz, cx, cy, cz); };
-
-    // ---- 3. march: up to S steps out of LDS -------------------------------------------------------------------
+  auto inside = [&](int cx, int cy, int cz) { return inside_of(LOx, LOy, LOz, cx, cy, cz); };
+  // ---- 3. march: up to S steps out of LDS.  TEST (SKIP builds): the window touches an empty macro cell, the mask is
+  // tested per step; in the other windows the test is compiled out
+  auto march = [&](auto test_tag) {
+    constexpr bool TEST = decltype(test_tag)::value;
 #pragma unroll 1
     for (int s = 0; s < S; ++s) {
       const bool go = is_alive() & inside(cxi, cyi, czi);
@@ -296,35 +378,16 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(PHONG ? VX_
       if (gm == 0ull) break;                      // nobody can step in this window any more: restage
       bool eval = go;
       float jump = 0.0f;   // SKIP: further steps this lane may pass over (all inside the same empty macro cell)
-      if (SKIP) {
-        uint32_t cx = (uint32_t)(cxi + 1), cy = (uint32_t)(cyi + 1), cz = (uint32_t)(czi + 1);
-        cx = cx < cmaxx ? cx : cmaxx; cy = cy < cmaxy ? cy : cmaxy; cz = cz < cmaxz ? cz : cmaxz;
-        uint32_t mi = ((cz >> sh) * md1 + (cy >> sh)) * md0 + (cx >> sh);
-        bool empty = (mask_lds[mi >> 5] >> (mi & 31u)) & 1u;
+      if (TEST) {
+        const bool empty = in_empty_cell();
         eval = go & !empty;
         const bool emp = go & empty;
         const unsigned long long em = ballot(emp);
         n_skipped += (uint32_t)__builtin_popcountll(em);
-        if (em != 0ull) {   // wave uniform
-          // distance (in t) from this sample to the faces of its macro cell, along the ray: the lane moves on to two
-          // steps short of the exit face (vx_dvr.hpp does the same with the last sample of a batch); every sample
-          // passed over lies inside the same empty macro cell, so the set of evaluated samples is unchanged
-          const float Sf = (float)(1u << sh);
-          const float bx = (float)((cx >> sh) << sh) - 1.0f, by = (float)((cy >> sh) << sh) - 1.0f,
-                      bz = (float)((cz >> sh) << sh) - 1.0f;   // q in [b, b + S) inside the macro cell
-          const float dx = r.idir.x > 0.0f ? (bx + Sf - qx) / r.idir.x : (r.idir.x < 0.0f ? (bx - qx) / r.idir.x : 3.0e38f);
-          const float dy = r.idir.y > 0.0f ? (by + Sf - qy) / r.idir.y : (r.idir.y < 0.0f ? (by - qy) / r.idir.y : 3.0e38f);
-          const float dz = r.idir.z > 0.0f ? (bz + Sf - qz) / r.idir.z : (r.idir.z < 0.0f ? (bz - qz) / r.idir.z : 3.0e38f);
-          float n = floorf(fminf(dx, fminf(dy, dz)) * inv_dt) - 2.0f;   // stay >= one whole step short of the exit face
-          n = fminf(n, 1048576.0f);
-          jump = (emp && n >= 1.0f) ? n : 0.0f;
-        }
+        if (em != 0ull) jump = jump_of(emp);      // wave uniform
       }
-      {
-        unsigned long long m = ballot(eval);
-        n_samples += (uint32_t)__builtin_popcountll(m);
-        n_slots += 64u;
-      }
+      n_slots += 64u;
+      n_samples += (uint32_t)__builtin_popcountll(ballot(eval));
       // word offset of the sample's cell in the tile; lanes that do not step read cell 0 (defined data)
       // go: all three differences are in [0, 16): 24-bit multiplies (full rate) instead of v_mul_lo_u32
       int off = (int)mad24((uint32_t)(czi - LOz), (uint32_t)SS, mad24((uint32_t)(cyi - LOy), (uint32_t)RS, (uint32_t)(cxi - LOx)));
@@ -401,13 +464,15 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(PHONG ? VX_
       kf = go ? kf + 1.0f + jump : kf;
       next_sample();
     }
+  };
+  while (true) {
+    if (ballot(is_alive()) == 0ull) break;
+    if (SKIP && wtest) march(std::integral_constant<bool, SKIP>{});
+    else march(std::false_type{});
     // ---- next window ------------------------------------------------------------------------------------------------
     const unsigned long long live = ballot(is_alive());
     if (live == 0ull) break;
-    exact_window(live);
-    float4 vals[TL::PASSES][NC];
-    issue_loads(LOx, LOy, LOz, vals);
-    write_tile(vals);
+    if (!next_window(live)) break;
   }
 
   if (in_image) dvr_store(p, v, r, Cx, Cy, Cz, T, weight, slab, si);
