@@ -41,6 +41,12 @@ def _render_with_params(r, p, frame=0, weight=0.0):
     return r.read_accum()
 
 
+def _oracle_env(oracle, r):
+    """the renderer's environment map as the oracle takes it (None: directional light)"""
+    e = r.environment
+    return oracle.Environment(e.floats, e.width, e.height) if e is not None else None
+
+
 def test_unorm_table():
     from volxel_amd import Volxel3DRenderer
     r = Volxel3DRenderer(64, 64)
@@ -804,6 +810,68 @@ def test_fullsize_properties(big_scene):
     #     -> equal to rendering the mirrored camera... (covered by oracle parity at small size)
 
 
+@pytest.mark.parametrize("mode", ["dvr", "dvr_phong"])
+def test_fullsize_config3_config4_match_live_oracle(big_scene, oracle, mode):
+    """BASELINE configs 3 and 4 at their full size -- 512^3, 1920x1080, clip box, ERT, per-frame jitter on; config 4
+    adds the central-difference gradient and Blinn-Phong -- against the CPU oracle on the same frame (16 host threads
+    render the 214 M samples of the frame in about a second): every pixel within the fp tolerance, exact sample,
+    ray and shaded-sample counts.  Frame 5 through a 3-frame launch, i.e. the multi-frame path and the blend."""
+    r, msg = big_scene
+    r.set_layout(3)
+    old = (r.settings.render_mode, r.settings.dvr_jitter, r.settings.dvr_skip_empty)
+    # config 3 marches every sample (the bench's setting); config 4 here with exact empty-space skipping on
+    r.settings.render_mode, r.settings.dvr_jitter, r.settings.dvr_skip_empty = mode, True, mode == "dvr_phong"
+    try:
+        p = r.bind_uniforms()
+        r.restart_rendering(); r.reset_counters()
+        r._check(r._lib.vx_render_frame(r._ctx, 5, 0.0))
+        img = r.read_accum(); c = r.counters()
+        vol = oracle.make_volume(msg)
+        want, oc = oracle.render(p, vol, *r._tf, frame_index=5, threads=16, env=_oracle_env(oracle, r))
+        # the composite's exp is the hardware's 1-ulp v_exp_f32, the oracle's libm's: over rays of up to 1500 samples
+        # the colour sums drift apart by a few 1e-6 (small cases: 2e-6) -- a tenth of BASELINE.md's 1e-4 budget
+        tol = 2e-5 if mode == "dvr_phong" else 1e-5
+        assert float(np.abs(img - want).max()) <= tol
+        assert (c.samples, c.rays, c.pixels) == (oc.samples, oc.rays, 1920 * 1080)
+        assert c.samples > (1.4e8 if r.settings.dvr_skip_empty else 2.1e8)
+        if mode == "dvr_phong":
+            assert c.grad_samples == oc.grad_samples and c.grad_samples > 1e7
+        # the same frame as the last of a 3-frame launch (weights 0: the accumulator keeps the last frame)
+        r.restart_rendering()
+        w = (C.c_float * 3)(0.0, 0.0, 0.0)
+        r._check(r._lib.vx_render_frames(r._ctx, 3, 3, w, 3))
+        assert np.array_equal(r.read_accum(), img)
+    finally:
+        r.settings.render_mode, r.settings.dvr_jitter, r.settings.dvr_skip_empty = old
+
+
+def test_fullsize_config2_ct_phantom_matches_live_oracle(oracle):
+    """BASELINE config 2 at its full size: 256^3 CT phantom through the native brick builder, 1920x1080, trilinear +
+    1-D transfer function, jitter on; exact empty-space skipping off and on (free flight over the air around the
+    body) against the CPU oracle on the same frame"""
+    from volxel_amd import BENCHMARK_SETTINGS, Volxel3DRenderer, read_u16_stack_to_grid, synth
+    vox, sp = synth.ct_phantom(256)
+    msg = read_u16_stack_to_grid(vox, sp)
+    r = Volxel3DRenderer(1920, 1080)
+    r.setup_from_grid(msg)
+    r.restore_settings(BENCHMARK_SETTINGS)       # benchmark.json: TF, histogram range, camera, multiplier
+    r.settings.render_mode, r.settings.dvr_jitter = "dvr", True
+    vol = oracle.make_volume(msg)
+    seen = []
+    for skip in (False, True):
+        r.settings.dvr_skip_empty = skip
+        p = r.bind_uniforms()
+        r.restart_rendering(); r.reset_counters()
+        r._check(r._lib.vx_render_frame(r._ctx, 2, 0.0))
+        img = r.read_accum(); c = r.counters()
+        want, oc = oracle.render(p, vol, *r._tf, frame_index=2, threads=16, env=_oracle_env(oracle, r))
+        assert float(np.abs(img - want).max()) <= 1e-5
+        assert (c.samples, c.rays) == (oc.samples, oc.rays)
+        seen.append((img, c.samples))
+    assert np.array_equal(seen[0][0], seen[1][0]) and seen[1][1] < 0.5 * seen[0][1]
+    r.close()
+
+
 def test_fullsize_tile_shards_are_bit_identical(big_scene):
     """image-space tiles: 3 shards rendered by 3 contexts on this GPU, slabs gathered
     (device-to-device) and de-tiled == the unsharded image, bit for bit"""
@@ -906,7 +974,7 @@ def huge_scene():
     r.close()
 
 
-def test_config5_1024_cubed_4k_eight_tile_shards(huge_scene):
+def test_config5_1024_cubed_4k_eight_tile_shards(huge_scene, oracle):
     """the brickf32 / LDS-window march, the 19.8 GB cellquad build, the 24-bit brick index arithmetic of the gather
     march, the 2040-tile dealing order and the multi-frame launch at their full size (brick.rs:77-81 sets the limits): every one of the 8 shards, dealt
     by the balanced order, reproduces its pixels of the unsharded 4K frame bit for bit; sample counts add up;
@@ -936,6 +1004,16 @@ def test_config5_1024_cubed_4k_eight_tile_shards(huge_scene):
         assert c1.samples == c0.samples and c1.rays == c0.rays, layout
         assert np.abs(ref - base).max() <= 2e-6, layout
     r.set_layout(3)
+    # against the CPU oracle: the centred 960x540 crop of frame 1 (a quarter of a billion samples)
+    p = r.bind_uniforms()
+    r.restart_rendering(); r.reset_counters()
+    r._check(r._lib.vx_render_frame(r._ctx, 1, 0.0))
+    img = r.read_accum()
+    x0, y0 = (3840 - 960) // 2, (2160 - 540) // 2
+    want, oc = oracle.render(p, oracle.make_volume(msg), *r._tf, frame_index=1, rect=(x0, x0 + 960, y0, y0 + 540),
+                             threads=16, env=_oracle_env(oracle, r))
+    assert oc.samples > 1e8
+    assert float(np.abs(img[y0:y0 + 540, x0:x0 + 960] - want[y0:y0 + 540, x0:x0 + 960]).max()) <= 1e-5
     # 8 shards through ONE extra context (re-sharded in place; the volume is replicated per GPU in production)
     N = 8
     rr = Volxel3DRenderer(3840, 2160, shard_rank=0, shard_count=N)
