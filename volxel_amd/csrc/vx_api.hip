@@ -57,6 +57,11 @@ struct VxContext {
   bool skip_dirty = true;
   float skip_key[4] = {0, 0, 0, 0};   // density_scale, inv_maj, sample_range
 
+  // default mode: local-majorant table (DevVolume::lmaj), rebuilt when its inputs change
+  float* lmaj_dev = nullptr;
+  bool lmaj_dirty = true;
+  float lmaj_key[5] = {0, 0, 0, 0, 0};   // density_scale, inv_maj, maj, sample_range
+
   // params
   VxParams params{};
   bool has_params = false;
@@ -149,6 +154,9 @@ static void free_volume(VxContext* c) {
   c->dv = DevVolume{};
   c->has_volume = false;
   c->skip_dirty = true;
+  if (c->lmaj_dev) (void)hipFree(c->lmaj_dev);
+  c->lmaj_dev = nullptr;
+  c->lmaj_dirty = true;
 }
 
 static void drain_events(VxContext* c) {
@@ -309,6 +317,27 @@ static void compute_skip_mask(const VxParams& p, const uint32_t* range_packed, c
           bits[i >> 5] |= 1u << (i & 31);
         }
       }
+}
+
+// the local majorants of the default mode, tabulated on the device with the operations of Frame::local_majorant
+static int rebuild_local_majorants(VxContext* c) {
+  const VxParams& p = c->params;
+  const size_t n = 4 * (size_t)c->dv.bc[0] * c->dv.bc[1] * c->dv.bc[2] + 1;
+  if (!c->lmaj_dev) VX_HIP(c, hipMalloc(&c->lmaj_dev, n * sizeof(float)));
+  DevVolume dv = c->dv;
+  dv.lmaj = nullptr;
+  hipLaunchKernelGGL(build_local_majorants, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, c->stream, p, dv, c->tf,
+                     c->tf_len, c->lmaj_dev);
+  VX_HIP(c, hipGetLastError());
+  c->dv.lmaj = c->lmaj_dev;
+  c->dv.lmaj_cells = (uint32_t)(n - 1);
+  c->lmaj_dirty = false;
+  c->lmaj_key[0] = p.volume_density_scale;
+  c->lmaj_key[1] = p.volume_inv_maj;
+  c->lmaj_key[2] = p.volume_maj;
+  c->lmaj_key[3] = p.sample_range[0];
+  c->lmaj_key[4] = p.sample_range[1];
+  return VX_OK;
 }
 
 static int rebuild_skip_mask(VxContext* c) {
@@ -866,6 +895,7 @@ int vx_upload_transfer(VxContext* c, const float* rgba, uint32_t length) {
   c->tf_len = length;
   c->tf_host.assign(rgba, rgba + (size_t)length * 4);
   c->skip_dirty = true;
+  c->lmaj_dirty = true;
   c->order_builds_left = 2;
   return VX_OK;
 }
@@ -1006,6 +1036,12 @@ static int prepare_render(VxContext* c, dim3& grid) {
         int rc = rebuild_skip_mask(c);
         if (rc) return rc;
       }
+    }
+    if (p.render_mode == VX_MODE_DEFAULT && !p.debug_hits &&
+        (c->lmaj_dirty || !c->dv.lmaj || c->lmaj_key[0] != p.volume_density_scale || c->lmaj_key[1] != p.volume_inv_maj ||
+         c->lmaj_key[2] != p.volume_maj || c->lmaj_key[3] != p.sample_range[0] || c->lmaj_key[4] != p.sample_range[1])) {
+      int rc = rebuild_local_majorants(c);
+      if (rc) return rc;
     }
   }
   {

@@ -39,6 +39,10 @@ struct DevVolume {
   uint32_t skip_level;
   uint32_t skip_dims[3];        // (extent >> (3 + level)) + 1
   uint32_t skip_words;
+  // default mode (A13): the local majorant maj * TF(scale * range max).a of every cell of range-texture levels 0..3
+  // (dda.glsl:36,78), levels back to back, each at the strides of level 0; entry lmaj_cells = the value outside
+  const float* lmaj;            // built by vx_api before a `default` launch (build_local_majorants)
+  uint32_t lmaj_cells;          // 4 * bricks
   // environment map (environment.ts): RGBA32F texels in GL row order + importance mip pyramid
   const float4* env_tex;        // nullptr: none (directional light only)
   uint32_t env_w, env_h;
@@ -304,34 +308,32 @@ VXD float lookup_density_trilinear(const DevVolume& v, float density_scale, V3 p
   return trilinear_cell<LAYOUT>(v, density_scale, f2i(flx), f2i(fly), f2i(flz), fx, fy, fz);
 }
 
-// lookup_majorant, common.glsl:50-53 (range texture level `mip`, .x = R = max)
-VXD float lookup_majorant(const DevVolume& v, float density_scale, V3 p, int mip) {
-  int sh = 3 + mip;
-  int bx = f2i(floorf(p.x)) >> sh, by = f2i(floorf(p.y)) >> sh, bz = f2i(floorf(p.z)) >> sh;
-  const uint32_t* data;
-  uint32_t sx, sy, sz;
-  if (mip == 0) {
-    data = v.range; sx = v.bc[0]; sy = v.bc[1]; sz = v.bc[2];
-  } else {
-    data = v.mips[mip - 1]; sx = v.mip_size[mip - 1][0]; sy = v.mip_size[mip - 1][1]; sz = v.mip_size[mip - 1][2];
-  }
-  float r = 0.0f;
-  if ((uint32_t)bx < sx && (uint32_t)by < sy && (uint32_t)bz < sz)
-    r = half_bits_to_float(data[((uint32_t)bz * sy + (uint32_t)by) * sx + (uint32_t)bx] & 0xffffu);
-  return density_scale * r;
+// lookup_majorant, common.glsl:50-53: the range-texture texel (level `mip`, .x = R = max) by cell, 0 outside the level
+VXD float range_max_texel(const DevVolume& v, int mip, uint32_t bx, uint32_t by, uint32_t bz) {
+  const uint32_t* data = mip == 0 ? v.range : v.mips[mip - 1];
+  const uint32_t sx = mip == 0 ? v.bc[0] : v.mip_size[mip - 1][0], sy = mip == 0 ? v.bc[1] : v.mip_size[mip - 1][1],
+                 sz = mip == 0 ? v.bc[2] : v.mip_size[mip - 1][2];
+  if (bx < sx && by < sy && bz < sz) return half_bits_to_float(data[(bz * sy + by) * sx + bx] & 0xffffu);
+  return 0.0f;
 }
 
 // A7: lookup_transfer, common.glsl:78-83; NEAREST + CLAMP_TO_EDGE (viewer.ts:386-389)
 struct TfView {
-  const float4* lut;  // LDS or global
+  const float4* lut;  // LDS (in_lds) or global
   uint32_t len;
   float lenf;
+  bool in_lds;        // wave uniform: the fetch is a ds_read_b128 or a global load, never a flat one
 };
+typedef const float4 __attribute__((address_space(3))) * LdsFloat4Ptr;
 VXD float4 lookup_transfer(const TfView& tf, const float sr0, const float sr1, float d) {
   if (d < sr0 || d > sr1) return make_float4(0.f, 0.f, 0.f, 0.f);
   int i = f2i(floorf(d * tf.lenf));
   i = i < 0 ? 0 : i;
   i = i > (int)tf.len - 1 ? (int)tf.len - 1 : i;
+  if (tf.in_lds) {
+    const LdsFloat4Ptr e = (LdsFloat4Ptr)tf.lut + i;
+    return make_float4(e->x, e->y, e->z, e->w);
+  }
   return tf.lut[i];
 }
 

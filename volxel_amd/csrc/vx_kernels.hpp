@@ -162,8 +162,10 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(generic_min
     for (uint32_t i = threadIdx.x; i < tf_len; i += blockDim.x) tf_lds[i] = tf_global[i];
     __syncthreads();
     tf.lut = tf_lds;
+    tf.in_lds = true;
   } else {
     tf.lut = tf_global;
+    tf.in_lds = false;
   }
   uint32_t fslot, blk;
   multi_slot(blockIdx.x, mo.count, fslot, blk);
@@ -202,6 +204,7 @@ __global__ __launch_bounds__(64) void probe_tile_costs(const VxParams p, const D
                                                         const TileMap tm, uint32_t* __restrict__ costs) {
   TfView tf;
   tf.lut = tf_global;
+  tf.in_lds = false;
   tf.len = tf_len;
   tf.lenf = (float)tf_len;
   const uint32_t t = blockIdx.x, lane = threadIdx.x & 63u;
@@ -393,6 +396,24 @@ __global__ __launch_bounds__(256) void build_importance_mip(float* __restrict__ 
 }
 
 // sibling quads of every level 0..8 for sample_environment: one thread per quad
+// local majorants of the default mode (Frame::local_majorant): one thread per (level, cell of level-0 strides);
+// the last entry is the value outside the grid (range texel 0)
+__global__ __launch_bounds__(256) void build_local_majorants(const VxParams p, const DevVolume v, const float4* __restrict__ tf,
+                                                             uint32_t tf_len, float* __restrict__ out) {
+  const uint32_t nb = v.bc[0] * v.bc[1] * v.bc[2];
+  const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i > 4u * nb) return;
+  float r = 0.0f;
+  if (i < 4u * nb) {
+    const uint32_t mip = i / nb, c = i - mip * nb;
+    const uint32_t bz = c / (v.bc[0] * v.bc[1]), rem = c - bz * v.bc[0] * v.bc[1], by = rem / v.bc[0], bx = rem - by * v.bc[0];
+    r = range_max_texel(v, (int)mip, bx, by, bz);
+  }
+  const TfView view{tf, tf_len, (float)tf_len, false};
+  const float m = p.volume_density_scale * r;   // lookup_majorant, common.glsl:50-53
+  out[i] = p.volume_maj * lookup_transfer(view, p.sample_range[0], p.sample_range[1], m * p.volume_inv_maj).w;
+}
+
 __global__ __launch_bounds__(256) void build_importance_quads(const float* __restrict__ pyr, float4* __restrict__ quads,
                                                                uint32_t level) {
   uint32_t half = IMP_DIM >> (level + 1), n = half * 2;

@@ -73,7 +73,8 @@ struct Frame {
   // ---- A13 default mode: sampling/dda.glsl ------------------------------------------
   VXD static float step_dda(V3 pos, V3 inv_dir, int mip) {  // dda.glsl:11-16
     float dim = (float)(8 << mip);
-    float inv_dim = 1.0f / dim;
+    // 1 / dim: dim is a power of two, its reciprocal is the float with exponent -(3 + mip) -- no division sequence
+    float inv_dim = __builtin_bit_cast(float, (uint32_t)(124 - mip) << 23);
     float ox = (inv_dir.x >= 0.0f) ? dim + 0.5f : -0.5f;
     float oy = (inv_dir.y >= 0.0f) ? dim + 0.5f : -0.5f;
     float oz = (inv_dir.z >= 0.0f) ? dim + 0.5f : -0.5f;
@@ -82,10 +83,21 @@ struct Frame {
     float tz = ((floorf(pos.z * inv_dim) * dim + oz) - pos.z) * inv_dir.z;
     return gl_min(tx, gl_min(ty, tz));
   }
+  // dda.glsl:36,78: u_volume_maj * lookup_transfer(lookup_majorant(curr, mip) * inv_maj).a.  The value is a pure
+  // function of the range-texture cell, the transfer function and four uniforms: vx_api tabulates it per cell with
+  // these same operations (build_local_majorants), so a DDA step costs one load instead of the dependent chain
+  // level dimensions -> range texel -> LUT entry.
   VXD float local_majorant(V3 curr, int mip) const {
-    float m = lookup_majorant(v, p.volume_density_scale, curr, mip);
-    return p.volume_maj * transfer(m * p.volume_inv_maj).w;
+    const int sh = 3 + mip;
+    const uint32_t bx = (uint32_t)(f2i(floorf(curr.x)) >> sh), by = (uint32_t)(f2i(floorf(curr.y)) >> sh),
+                   bz = (uint32_t)(f2i(floorf(curr.z)) >> sh);
+    const bool in = bx < v.bc[0] && by < v.bc[1] && bz < v.bc[2];
+    // 24-bit multiplies: at most 128 bricks per axis (brick.rs:77-81), four levels
+    const uint32_t i = mad24(mad24(mad24((uint32_t)mip, v.bc[2], bz), v.bc[1], by), v.bc[0], bx);
+    return v.lmaj[in ? i : v.lmaj_cells];   // the entry after the last level holds the value outside the grid
   }
+  // round(mip), half away from zero (quirk Q12): mip is a multiple of 1/4 in [0, 3], so floor(mip + 1/2) is the same
+  VXD static int round_mip(float mip) { return f2i(mip + 0.5f); }
   VXD float transmittance_dda(const Ray& ray, Rng& s) const {  // dda.glsl:21-62
     float near, far;
     if (!slab(ray, near, far)) return 1.0f;
@@ -96,7 +108,7 @@ struct Frame {
     uint32_t step = 0;
     while (t < far && (step++ < 100u)) {
       V3 curr = madd3(ipos, t, idir);
-      int m = f2i(roundf(mip));  // round half away from zero (quirk Q12)
+      int m = round_mip(mip);
       float majorant = local_majorant(curr, m);
       float dt = step_dda(curr, ri, m);
       c.skips++;
@@ -133,7 +145,7 @@ struct Frame {
     uint32_t guard = 0;  // the reference loop is unbounded; a wedged wave would hang the GPU
     while (t < far && guard++ < LOOP_GUARD) {
       V3 curr = madd3(ipos, t, idir);
-      int m = f2i(roundf(mip));
+      int m = round_mip(mip);
       float majorant = local_majorant(curr, m);
       float dt = step_dda(curr, ri, m);
       c.skips++;

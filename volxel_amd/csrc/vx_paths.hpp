@@ -44,8 +44,10 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(VX_W_PATHS,
   if (tf_len <= TF_LDS_MAX) {
     for (uint32_t i = threadIdx.x; i < tf_len; i += blockDim.x) tf_lds[i] = tf_global[i];
     tf.lut = tf_lds;
+    tf.in_lds = true;
   } else {
     tf.lut = tf_global;
+    tf.in_lds = false;
   }
   __syncthreads();
   uint32_t fslot, blk;
