@@ -46,7 +46,7 @@ BYTES_PER_SAMPLE = 16.0    # 8 x 1 B voxels + 4 B range + 4 B in
 BYTES_PER_PIXEL_RESULT = 16.0   # RGBA32F result written by the render kernel (one frame of one launch)
 BYTES_PER_PIXEL_BLEND = 32.0    # accumulator read + write by the blend (+32 B per pixel per frame
                                 # = this + nothing else when a frame is blended in the render kernel itself)
-DEFAULT_FRAMES_PER_LAUNCH = 16
+DEFAULT_FRAMES_PER_LAUNCH = 32
 KERNEL = {None: "vx::render_dvr_lds<16>", 0: "vx::render_generic<3,0>", 1: "vx::render_dvr_cq<4>", 2: "vx::render_dvr_lds<16>"}
 LAYOUT = {None: "brickf32", 0: "reference", 1: "cellquad", 2: "brickf32"}   # None = VX_LAYOUT_AUTO: DVR marches brickf32
 
@@ -231,8 +231,12 @@ def main():
     ap.add_argument("--gather-every", type=int, default=64,
                     help="N>1: all_gather the framebuffer once per this many accumulation frames")
     ap.add_argument("--frames-per-launch", type=int, default=None,
-                    help="independent accumulation frames rendered by one kernel launch (1..64); default 16 x the "
-                         "number of ranks (a launch then carries the same work per GPU whatever N), at most 64")
+                    help="independent accumulation frames rendered by one kernel launch (1..64); default 32 x the "
+                         "number of ranks, at most 64 (what the library takes per launch)")
+    ap.add_argument("--precondition-ms", type=float, default=150.0,
+                    help="keep the device busy with untimed frames of the same workload for this long before the W warm-up "
+                         "steps, so that the timed region runs at the clock the chip sustains (an MI355X drops its clocks within "
+                         "a millisecond of idling: tools/fpl_sweep.py --sync); 0 = off; reported as config.preconditioning")
     ap.add_argument("--no-jitter", action="store_true",
                     help="diagnostic: pixel-centre rays, identical in every frame (NOT the reference's behaviour)")
     ap.add_argument("--no-skip-variant", action="store_true", help="do not run the secondary measurement with skipping")
@@ -338,6 +342,19 @@ def main():
         if need_image and use_dist and state["gathers"] == before:
             gather()                          # a timed run always delivers at least one gathered image
 
+    # device preconditioning: the chip idled while the host generated the volume; a few ms of warm-up steps do not
+    # bring it back to the clock it sustains under load (measured: 0.36 instead of 0.31 ms per frame)
+    pre = {"frames": 0, "seconds": 0.0}
+    if a.precondition_ms > 0:
+        t_pre = time.perf_counter()
+        while time.perf_counter() - t_pre < a.precondition_ms * 1e-3:
+            r.render(frames=P, rebind=False, in_flight=P)
+            r.finish()
+            pre["frames"] += P
+        pre["seconds"] = round(time.perf_counter() - t_pre, 3)
+        r.restart_rendering()
+        r.bind_uniforms()
+
     # the first two frames (re)build the launch order; the warm-up also performs one gather, so that RCCL's
     # first-use setup of the collective is not inside the timed region
     run(0, max(a.warmup, 2), need_image=True)
@@ -425,6 +442,8 @@ def main():
                 "samples_per_frame": int(samples // a.steps),
                 "frames_per_launch": fpl, "frames_per_launch_requested": P,
                 "timed_region_s": round(elapsed, 4),
+                "preconditioning": {**pre, "note": "untimed frames of the same workload before the warm-up steps: the timed "
+                                    "region then runs at the clock the chip sustains under load (--precondition-ms 0: off)"},
                 "lane_utilisation": round(c.samples / c.lane_slots, 4) if c.lane_slots else None,
                 "device": name, "cus": cus, **info,
             },

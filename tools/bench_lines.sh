@@ -18,7 +18,7 @@ run() {  # note, args...
 }
 LEAN="--no-cpu-baseline --no-mode-variants --no-skip-variant"
 run "the driver's command" --gpus 1 --steps 20 --warmup 5 &&
-run "16 frames per launch: 8 launches" --steps 128 --warmup 5 --no-cpu-baseline &&
+run "32 frames per launch: 4 launches" --steps 128 --warmup 5 --no-cpu-baseline &&
 run "64 frames per launch" --steps 128 --warmup 5 --frames-per-launch 64 $LEAN &&
 run "cellquad gather kernel" --gpus 1 --steps 20 --warmup 5 --layout 1 $LEAN &&
 run "BASELINE config 5 workload, whole frame on one GPU" --volume 1024 --width 3840 --height 2160 --steps 20 --warmup 5 --no-cpu-baseline --no-mode-variants &&

@@ -62,6 +62,8 @@ struct VxContext {
   bool lmaj_dirty = true;
   float lmaj_key[5] = {0, 0, 0, 0, 0};   // density_scale, inv_maj, maj, sample_range
 
+  unsigned long long* fold_dev = nullptr;   // eight totals of fold_records
+
   // params
   VxParams params{};
   bool has_params = false;
@@ -364,31 +366,33 @@ static int rebuild_skip_mask(VxContext* c) {
 }
 
 
-static void add_record(VxCounters& t, const DevCounters& w) {
-  t.samples += w.samples;
-  t.lane_slots += w.slots;
-  t.rays += w.rays;
-  t.pixels += w.pixels;
-  t.skip_steps += w.skips;
-  t.grad_samples += w.grads;
-  t.gathers += w.gathers;
-  t.lds_reads += w.lds_reads;
-}
-
+// fold every record array (accumulator slot and pipeline slots) into c->base on the device and zero it
 static int fold_counters(VxContext* c) {
   if (!c->dc || !c->dc_waves) return VX_OK;
-  std::vector<DevCounters> h(c->dc_waves);
-  VX_HIP(c, hipMemcpy(h.data(), c->dc, h.size() * sizeof(DevCounters), hipMemcpyDeviceToHost));
-  for (const auto& w : h) add_record(c->base, w);
-  VX_HIP(c, hipMemset(c->dc, 0, c->dc_waves * sizeof(DevCounters)));
+  if (!c->fold_dev) VX_HIP(c, hipMalloc(&c->fold_dev, 8 * sizeof(unsigned long long)));
+  VX_HIP(c, hipMemsetAsync(c->fold_dev, 0, 8 * sizeof(unsigned long long), c->stream));
+  auto fold = [&](DevCounters* recs, size_t n) {
+    const unsigned blocks = (unsigned)std::min<size_t>((n + 255) / 256, 2048);
+    hipLaunchKernelGGL(fold_records, dim3(blocks), dim3(256), 0, c->stream, recs, n, c->fold_dev);
+  };
+  fold(c->dc, c->dc_waves);
   for (auto& p : c->pipes) {
     if (!p.dc) continue;
     if (p.stream) VX_HIP(c, hipStreamSynchronize(p.stream));
-    std::vector<DevCounters> hp(c->pipe_waves);
-    VX_HIP(c, hipMemcpy(hp.data(), p.dc, hp.size() * sizeof(DevCounters), hipMemcpyDeviceToHost));
-    for (const auto& w : hp) add_record(c->base, w);
-    VX_HIP(c, hipMemset(p.dc, 0, c->pipe_waves * sizeof(DevCounters)));
+    fold(p.dc, c->pipe_waves);
   }
+  VX_HIP(c, hipGetLastError());
+  unsigned long long h[8];
+  VX_HIP(c, hipMemcpyAsync(h, c->fold_dev, sizeof h, hipMemcpyDeviceToHost, c->stream));
+  VX_HIP(c, hipStreamSynchronize(c->stream));
+  c->base.samples += h[0];
+  c->base.lane_slots += h[1];
+  c->base.rays += h[2];
+  c->base.pixels += h[3];
+  c->base.skip_steps += h[4];
+  c->base.grad_samples += h[5];
+  c->base.gathers += h[6];
+  c->base.lds_reads += h[7];
   return VX_OK;
 }
 
@@ -532,6 +536,7 @@ void vx_destroy(VxContext* c) {
   if (c->env_imp) (void)hipFree(c->env_imp);
   if (c->env_impq) (void)hipFree(c->env_impq);
   if (c->skip_dev) (void)hipFree(c->skip_dev);
+  if (c->fold_dev) (void)hipFree(c->fold_dev);
   if (c->slab) (void)hipFree(c->slab);
   if (c->image) (void)hipFree(c->image);
   if (c->display) (void)hipFree(c->display);
@@ -1128,16 +1133,14 @@ static int ensure_pipes(VxContext* c, int n) {
   size_t waves = c->dc_waves;
   if ((int)c->pipes.size() >= n && c->pipe_quads == c->slab_quads && c->pipe_waves == waves) return VX_OK;
   VX_HIP(c, hipStreamSynchronize(c->stream));
+  {
+    int rc = fold_counters(c);   // keep what the records of the old slots have counted
+    if (rc) return rc;
+  }
   for (auto& p : c->pipes) {
     if (p.stream) (void)hipStreamSynchronize(p.stream);
     if (p.result) (void)hipFree(p.result);
-    if (p.dc) {
-      // keep what these records have counted
-      std::vector<DevCounters> h(c->pipe_waves);
-      if (hipMemcpy(h.data(), p.dc, h.size() * sizeof(DevCounters), hipMemcpyDeviceToHost) == hipSuccess)
-        for (const auto& w : h) add_record(c->base, w);
-      (void)hipFree(p.dc);
-    }
+    if (p.dc) (void)hipFree(p.dc);
     p.result = nullptr;
     p.dc = nullptr;
   }

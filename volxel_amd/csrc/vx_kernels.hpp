@@ -70,6 +70,25 @@ struct DevCounters {
   uint32_t pad;
 };
 
+// sums the per-wave records of one launch slot into eight 64-bit totals and zeroes them (vx_get_counters /
+// vx_reset_counters: 64 bytes cross PCIe instead of every record)
+__global__ __launch_bounds__(256) void fold_records(DevCounters* __restrict__ recs, size_t n,
+                                                    unsigned long long* __restrict__ sums) {
+  unsigned long long s[8] = {0ull, 0ull, 0ull, 0ull, 0ull, 0ull, 0ull, 0ull};
+  for (size_t i = (size_t)blockIdx.x * 256u + threadIdx.x; i < n; i += (size_t)gridDim.x * 256u) {
+    const DevCounters r = recs[i];
+    s[0] += r.samples; s[1] += r.slots; s[2] += r.rays; s[3] += r.pixels;
+    s[4] += r.skips; s[5] += r.grads; s[6] += r.gathers; s[7] += r.lds_reads;
+    recs[i] = DevCounters{};
+  }
+#pragma unroll
+  for (int k = 0; k < 8; ++k) {
+    unsigned long long x = s[k];
+    for (int off = 32; off > 0; off >>= 1) x += __shfl_xor(x, off);
+    if ((threadIdx.x & 63u) == 0u && x != 0ull) atomicAdd(&sums[k], x);
+  }
+}
+
 // `block` = logical block id (identical to blockIdx.x unless the launch is permuted by `order`)
 VXD void add_counts(DevCounters* dc, uint32_t samples, uint32_t rays, uint32_t pixels, uint32_t skips,
                     uint32_t grads, uint32_t slots, uint32_t block = 0xffffffffu, uint32_t gathers = 0u,
