@@ -323,14 +323,18 @@ def main():
             state["gathers"] += 1
 
     def fence():
-        r.finish()
+        tt = [time.perf_counter()]
+        r.finish(); tt.append(time.perf_counter())
         if state["work"] is not None:
             state["work"].wait()
-        torch.cuda.synchronize()
+        torch.cuda.synchronize(); tt.append(time.perf_counter())
         if use_dist:
             dist.barrier(device_ids=[local])
+        tt.append(time.perf_counter())
         r.finish()
-        torch.cuda.synchronize()
+        torch.cuda.synchronize(); tt.append(time.perf_counter())
+        if os.environ.get("VX_BENCH_TRACE"):
+            sys.stderr.write("fence: " + " ".join(f"{(b - a) * 1e3:.3f}" for a, b in zip(tt, tt[1:])) + " ms\n")
 
     def run(first, count, need_image=False, per_launch=P):
         done, before = 0, state["gathers"]
@@ -342,6 +346,10 @@ def main():
         if need_image and use_dist and state["gathers"] == before:
             gather()                          # a timed run always delivers at least one gathered image
 
+    if use_dist:
+        # RCCL's first barrier sets the collective up (12 ms measured): here, not in the fence before the timed region,
+        # where it would leave the device idle
+        dist.barrier(device_ids=[local])
     # device preconditioning: the chip idled while the host generated the volume; a few ms of warm-up steps do not
     # bring it back to the clock it sustains under load (measured: 0.36 instead of 0.31 ms per frame)
     pre = {"frames": 0, "seconds": 0.0}

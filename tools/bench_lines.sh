@@ -23,4 +23,5 @@ run "64 frames per launch" --steps 128 --warmup 5 --frames-per-launch 64 $LEAN &
 run "cellquad gather kernel" --gpus 1 --steps 20 --warmup 5 --layout 1 $LEAN &&
 run "BASELINE config 5 workload, whole frame on one GPU" --volume 1024 --width 3840 --height 2160 --steps 20 --warmup 5 --no-cpu-baseline --no-mode-variants &&
 run "config 5 workload, cellquad gather kernel" --volume 1024 --width 3840 --height 2160 --steps 20 --warmup 5 --layout 1 $LEAN &&
-run "RCCL gather path with one rank" --gpus 1 --steps 20 --warmup 5 --force-gather $LEAN
+run "RCCL gather path with one rank" --gpus 1 --steps 20 --warmup 5 --force-gather $LEAN &&
+run "the driver's command without device preconditioning: the chip still at its idle clocks" --gpus 1 --steps 20 --warmup 5 --precondition-ms 0 $LEAN
