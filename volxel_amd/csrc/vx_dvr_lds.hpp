@@ -450,14 +450,19 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(PHONG ? VX_
           }
         }
         // tau += a*maj*dt; C += (T_prev - T) * rgb   (raymarch.glsl:43 / SURVEY A12) -- straight line, as vx_dvr.hpp
+        // No select on `contrib`: T is always exp2(-tau * log2 e) of the lane's current tau (1 at tau = 0; a lane that is
+        // never sampled again keeps both), so a sample with alpha = 0 -- tau unchanged: fma(0, dt, tau) == tau --
+        // recomputes the same T, dT = T - T = +0 and C += 0 * rgb leaves C as it is
         tau = fma_(alpha * maj, r.dt, tau);
         const float Tn = __builtin_amdgcn_exp2f(tau * -1.4426950408889634f);
-        const float dT = contrib ? T - Tn : 0.0f;
+        const float dT = T - Tn;
         Cx = fma_(dT, rgba.x, Cx);
         Cy = fma_(dT, rgba.y, Cy);
         Cz = fma_(dT, rgba.z, Cz);
+        T = Tn;
+        // early ray termination (contrib && tau >= ert): the lane dies (far = -inf); its T stays exp2(-tau log2 e), so
+        // that later steps of the wave leave its C alone, and becomes 0 after the march
         const bool done = contrib && (tau >= ert);
-        T = contrib ? (done ? 0.0f : Tn) : T;
         far = done ? -__builtin_inff() : far;
       }
       // the lanes that stepped move on to their next sample
@@ -475,6 +480,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(PHONG ? VX_
     if (!next_window(live)) break;
   }
 
+  // a ray that terminated early (hit, yet far = -inf) is opaque: T = 0 (vx_modes.hpp Frame::dvr)
+  if (hit0 && far == -__builtin_inff()) T = 0.0f;
   if (in_image) dvr_store(p, v, r, Cx, Cy, Cz, T, weight, slab, si);
   const uint32_t n_px = (uint32_t)__builtin_popcountll(ballot(in_image));
   add_counts(dc, n_samples, n_rays, n_px, n_skipped, n_grads, n_slots, blk, n_loads, n_reads);
