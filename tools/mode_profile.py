@@ -12,4 +12,4 @@ r.bind_uniforms()
 r.render(frames=2, rebind=False); r.finish(); r.reset_counters()
 r.render(frames=32, rebind=False, in_flight=16); r.finish()
 c = r.counters()
-print(mode, "ms/frame", c.kernel_ms / c.frames, "Msamples", c.samples / c.frames / 1e6)
+print(mode, "ms/frame", c.kernel_ms / c.frames, "Msamples", c.samples / c.frames / 1e6, "pixels/frame", c.pixels / c.frames, "launches", c.launches, "frames", c.frames)

@@ -370,7 +370,7 @@ static int rebuild_skip_mask(VxContext* c) {
 static int fold_counters(VxContext* c) {
   if (!c->dc || !c->dc_waves) return VX_OK;
   if (!c->fold_dev) VX_HIP(c, hipMalloc(&c->fold_dev, 8 * sizeof(unsigned long long)));
-  VX_HIP(c, hipMemsetAsync(c->fold_dev, 0, 8 * sizeof(unsigned long long), c->stream));
+  hipLaunchKernelGGL(zero_totals, dim3(1), dim3(8), 0, c->stream, c->fold_dev);
   auto fold = [&](DevCounters* recs, size_t n) {
     const unsigned blocks = (unsigned)std::min<size_t>((n + 255) / 256, 2048);
     hipLaunchKernelGGL(fold_records, dim3(blocks), dim3(256), 0, c->stream, recs, n, c->fold_dev);
@@ -382,9 +382,9 @@ static int fold_counters(VxContext* c) {
     fold(p.dc, c->pipe_waves);
   }
   VX_HIP(c, hipGetLastError());
-  unsigned long long h[8];
-  VX_HIP(c, hipMemcpyAsync(h, c->fold_dev, sizeof h, hipMemcpyDeviceToHost, c->stream));
   VX_HIP(c, hipStreamSynchronize(c->stream));
+  unsigned long long h[8];
+  VX_HIP(c, hipMemcpy(h, c->fold_dev, sizeof h, hipMemcpyDeviceToHost));
   c->base.samples += h[0];
   c->base.lane_slots += h[1];
   c->base.rays += h[2];
@@ -405,7 +405,10 @@ static int ensure_counters(VxContext* c, size_t waves) {
   c->dc = nullptr;
   c->dc_waves = 0;
   VX_HIP(c, hipMalloc(&c->dc, waves * sizeof(DevCounters)));
-  VX_HIP(c, hipMemset(c->dc, 0, waves * sizeof(DevCounters)));
+  // on the context's stream: it is a non-blocking stream, a fill on the null stream is not ordered with the launches
+  // that follow (seen under rocprofv3's counter collection: the late fill wiped the records of a launch)
+  VX_HIP(c, hipMemsetAsync(c->dc, 0, waves * sizeof(DevCounters), c->stream));
+  VX_HIP(c, hipStreamSynchronize(c->stream));
   c->dc_waves = waves;
   if (c->order) (void)hipFree(c->order);
   c->order = nullptr;
@@ -1154,8 +1157,9 @@ static int ensure_pipes(VxContext* c, int n) {
     p.has_merged = false;
     VX_HIP(c, hipMalloc(&p.result, c->slab_quads * sizeof(float4)));
     VX_HIP(c, hipMalloc(&p.dc, waves * sizeof(DevCounters)));
-    VX_HIP(c, hipMemset(p.dc, 0, waves * sizeof(DevCounters)));
+    VX_HIP(c, hipMemsetAsync(p.dc, 0, waves * sizeof(DevCounters), c->stream));   // ordered with the launches
   }
+  VX_HIP(c, hipStreamSynchronize(c->stream));   // the fills are done before any stream launches into the new slots
   c->pipe_quads = c->slab_quads;
   c->pipe_waves = waves;
   return VX_OK;

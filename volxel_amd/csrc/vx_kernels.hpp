@@ -70,6 +70,8 @@ struct DevCounters {
   uint32_t pad;
 };
 
+__global__ void zero_totals(unsigned long long* sums) { sums[threadIdx.x] = 0ull; }
+
 // sums the per-wave records of one launch slot into eight 64-bit totals and zeroes them (vx_get_counters /
 // vx_reset_counters: 64 bytes cross PCIe instead of every record)
 __global__ __launch_bounds__(256) void fold_records(DevCounters* __restrict__ recs, size_t n,
