@@ -846,12 +846,19 @@ def test_fullsize_config3_config4_match_live_oracle(big_scene, oracle, mode):
 
 
 def test_fullsize_config2_ct_phantom_matches_live_oracle(oracle):
-    """BASELINE config 2 at its full size: 256^3 CT phantom through the native brick builder, 1920x1080, trilinear +
-    1-D transfer function, jitter on; exact empty-space skipping off and on (free flight over the air around the
-    body) against the CPU oracle on the same frame"""
-    from volxel_amd import BENCHMARK_SETTINGS, Volxel3DRenderer, read_u16_stack_to_grid, synth
+    """BASELINE config 2 at its full size: a 256^3 CT stack as 256 DICOM slices (explicit VR little endian, 12 bits
+    stored) through the native DICOM reader and brick builder, 1920x1080, trilinear + 1-D transfer function, jitter on;
+    exact empty-space skipping off and on (free flight over the air around the body) against the CPU oracle on the
+    same frame"""
+    from tests.dicom_writer import write_slice
+    from volxel_amd import BENCHMARK_SETTINGS, Volxel3DRenderer, read_dicoms_to_grid, read_u16_stack_to_grid, synth
     vox, sp = synth.ct_phantom(256)
-    msg = read_u16_stack_to_grid(vox, sp)
+    files = [write_slice(vox[z], spacing=(sp[0], sp[1]), thickness=sp[2]) for z in range(vox.shape[0])]
+    msg = read_dicoms_to_grid(files)
+    ref = read_u16_stack_to_grid(vox, sp)             # the same voxels handed over as a decoded stack
+    for f in ("indirection", "range", "atlas", "index_extent", "atlas_size"):
+        assert np.array_equal(np.asarray(getattr(msg, f)), np.asarray(getattr(ref, f))), f
+    del files, ref
     r = Volxel3DRenderer(1920, 1080)
     r.setup_from_grid(msg)
     r.restore_settings(BENCHMARK_SETTINGS)       # benchmark.json: TF, histogram range, camera, multiplier
