@@ -378,6 +378,50 @@ def test_progressive_accumulation_matches_oracle(oracle):
     assert np.abs(r2.read_accum() - prev).max() <= 4e-6
 
 
+@pytest.mark.parametrize("mode", ["default", "dvr"])
+def test_derived_tables_follow_their_inputs(oracle, mode):
+    """The library keeps tables derived from the transfer function and a few uniforms -- the local majorants of the
+    `default` mode's DDA (dda.glsl:36,78) and the macro-cell mask of the exact empty-space skipping -- and rebuilds
+    them when an input changes: after every change of TF, sample range, density multiplier or volume on ONE context
+    the frame equals that of a fresh context, bit for bit, sample counts included."""
+    from tests.common import make_scene, benchmark_tf, BENCH_CAM, small_noise
+    from volxel_amd import Volxel3DRenderer, default_transfer_function
+    grids = [oracle.BrickGrid(*small_noise(64, seed=9)), oracle.BrickGrid(*small_noise(48, seed=4))]
+    tfs = [benchmark_tf(), default_transfer_function()]
+    steps = [dict(g=0, tf=0, sample_range=(0.05, 1.0), density_multiplier=1.0),
+             dict(g=0, tf=1, sample_range=(0.05, 1.0), density_multiplier=1.0),      # another transfer function
+             dict(g=0, tf=1, sample_range=(0.3, 1.0), density_multiplier=1.0),       # another sample range
+             dict(g=0, tf=1, sample_range=(0.3, 1.0), density_multiplier=0.6),       # another density scale / majorant
+             dict(g=1, tf=1, sample_range=(0.3, 1.0), density_multiplier=0.6),       # another volume
+             dict(g=1, tf=0, sample_range=(0.05, 1.0), density_multiplier=1.0)]      # everything back at once
+
+    def frame(r, st, fresh):
+        if fresh or r.volume is None or st["g"] != frame.g:
+            r.setup_from_grid(grids[st["g"]])
+        frame.g = st["g"]
+        r.change_transfer_func(*tfs[st["tf"]])
+        r.settings.render_mode, r.settings.bounces = mode, 2
+        r.settings.dvr_skip_empty = True
+        r.settings.sample_range = st["sample_range"]
+        r.settings.density_multiplier = st["density_multiplier"]
+        r.camera.pos = np.asarray(BENCH_CAM["cam_pos"], dtype=np.float64)
+        r.camera.view = np.asarray(BENCH_CAM["look_at"], dtype=np.float64)
+        r.restart_rendering(); r.reset_counters()
+        r.render(frames=2)
+        c = r.counters()
+        return r.read_accum(), c.samples, c.skip_steps
+
+    frame.g = None
+    kept = Volxel3DRenderer(96, 64)
+    for i, st in enumerate(steps):
+        a = frame(kept, st, False)
+        fresh = Volxel3DRenderer(96, 64)
+        b = frame(fresh, st, True)
+        fresh.close()
+        assert np.array_equal(a[0], b[0]) and a[1:] == b[1:] and a[1] > 0, (mode, i)
+    kept.close()
+
+
 @pytest.mark.parametrize("layout", [0, 1, 2])
 def test_empty_space_skipping_is_exact(oracle, layout):
     """skipping on/off: identical pixels, sample counts equal to the oracle's in both settings"""
