@@ -47,6 +47,15 @@ if os.path.exists(bj) and os.path.getsize(bj):
         line = None
 # the launches bench.py timed have frames_per_launch x (blocks of one frame) x 256 threads
 fpl = line["roofline"]["frames_per_launch"] if line else None
+if line and by:
+    g1 = min(by)
+    gt = g1 * fpl if g1 * fpl in by else max(by)
+    v = by[gt]
+    print("\n## the timed launches")
+    print(f"The --stats average above mixes every launch of the kernel: device preconditioning and the other untimed")
+    print(f"launches (other frames per launch), warm-up, the single-frame side measurement.  bench.py timed the {len(v)} launch(es)")
+    print(f"of {fpl} frames = grid {gt}: kernel trace mean {sum(v)/len(v):.4f} ms; bench.py (HIP events, same run) "
+          f"roofline.avg_kernel_ms {line['roofline']['avg_kernel_ms']}")
 print("\n## PMC counters: per-dispatch mean over the timed dispatches of the kernel")
 means = {}
 for d in sorted(glob.glob(os.path.join(root, "*"))):
