@@ -41,7 +41,7 @@ namespace vx {
 #define VX_LDS_D 8
 #endif
 #ifndef VX_LDS_DP
-#define VX_LDS_DP 11
+#define VX_LDS_DP 10
 #endif
 #ifndef VX_LDS_X
 #define VX_LDS_X 12
@@ -57,7 +57,7 @@ struct LdsTile {
   static constexpr int RS = (X % 8 == 4) ? X : X + 4;             // row stride in words, = 4 mod 8
   static constexpr int SS = (Y * RS + 31 - 28) / 32 * 32 + 28;    // slice stride in words: >= Y * RS, = 28 mod 32
   static constexpr int ROWS = Y * Z;
-  static constexpr int FLOATS = SS * Z;          // 3968 B (DVR) / 6864 B (Phong) per wave
+  static constexpr int FLOATS = SS * Z;          // 3968 B (DVR) / 4960 B (Phong) per wave
   static constexpr int PASSES = (ROWS + 63) / 64;
   static constexpr int LO_MARGIN = PHONG ? 1 : 0;   // cells below the sample's cell that must be resident
   static constexpr int HI_MARGIN = PHONG ? 2 : 1;   // taps above it (x+1; x+2 for the gradient)
@@ -104,10 +104,10 @@ VXD float mix8(float v000, float v100, float v010, float v110, float v001, float
 #define VX_W_LDS_SKIP 6
 #endif
 #ifndef VX_W_LDS_PHONG
-#define VX_W_LDS_PHONG 1
+#define VX_W_LDS_PHONG 7
 #endif
 template <int S, bool PHONG, bool SKIP>
-__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(PHONG ? VX_W_LDS_PHONG : (SKIP ? VX_W_LDS_SKIP : VX_W_LDS), 8))) void render_dvr_lds(const VxParams p, const DevVolume v,
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(PHONG ? (SKIP ? 1 : VX_W_LDS_PHONG) : (SKIP ? VX_W_LDS_SKIP : VX_W_LDS), 8))) void render_dvr_lds(const VxParams p, const DevVolume v,
                                                        const float4* __restrict__ tf_global, uint32_t tf_len,
                                                        const MultiOut mo, float weight, const TileMap tm,
                                                        const uint32_t* __restrict__ order) {
