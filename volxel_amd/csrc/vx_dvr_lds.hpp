@@ -387,11 +387,13 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(PHONG ? (SK
         if (em != 0ull) jump = jump_of(emp);      // wave uniform
       }
       n_slots += 64u;
-      n_samples += (uint32_t)__builtin_popcountll(ballot(eval));
-      // word offset of the sample's cell in the tile; lanes that do not step read cell 0 (defined data)
-      // go: all three differences are in [0, 16): 24-bit multiplies (full rate) instead of v_mul_lo_u32
-      int off = (int)mad24((uint32_t)(czi - LOz), (uint32_t)SS, mad24((uint32_t)(cyi - LOy), (uint32_t)RS, (uint32_t)(cxi - LOx)));
-      off = go ? off : (TL::LO_MARGIN * (SS + RS + 1));
+      // (without skipping a lane evaluates one sample per step it takes: its count is kf after the march; counting
+      // per step costs a select and a compare to turn the conjunction `go` into a lane mask)
+      if (SKIP) n_samples += (uint32_t)__builtin_popcountll(ballot(eval));
+      // word offset of the sample's cell in the tile.  Stepping lanes: all three differences are in [0, 16): 24-bit
+      // multiplies (full rate) instead of v_mul_lo_u32.  The other lanes read wherever their stale cell points: an LDS
+      // read cannot fault (out of range it returns 0), and whatever they read ends in alpha = 0 (in_range has `go`).
+      const int off = (int)mad24((uint32_t)(czi - LOz), (uint32_t)SS, mad24((uint32_t)(cyi - LOy), (uint32_t)RS, (uint32_t)(cxi - LOx)));
       const float* tp = tile + off;
       const float* tq = tp + SS;                  // slice z + 1
       const float v000 = tp[0], v100 = tp[1], v010 = tp[RS], v110 = tp[RS + 1];
@@ -480,6 +482,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(PHONG ? (SK
     if (!next_window(live)) break;
   }
 
+  if (!SKIP) n_samples = wave_sum((uint32_t)kf);   // kf <= 2^24: exact; lane 0 holds the sum (add_counts reads it there)
   // a ray that terminated early (hit, yet far = -inf) is opaque: T = 0 (vx_modes.hpp Frame::dvr)
   if (hit0 && far == -__builtin_inff()) T = 0.0f;
   if (in_image) dvr_store(p, v, r, Cx, Cy, Cz, T, weight, slab, si);
