@@ -413,6 +413,9 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(PHONG ? (SK
       // the composite sit behind one wave-uniform branch -- 22 of the 85 vector instructions of a step
       const bool in_range = eval & !(dn < sr0 || dn > sr1);
       if (ballot(in_range) != 0ull) {
+#ifdef VX_COUNT_INRANGE   // diagnostic build: skip_steps counts the wave steps that enter this block
+        if (!SKIP) n_skipped += 1u;
+#endif
         const int ti = clamp0_i32((int)(dn * lenf), last);   // dn >= 0: truncation == floor
         float4 rgba = tf_lds[ti];
         const float alpha = in_range ? rgba.w : 0.0f;
