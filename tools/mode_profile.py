@@ -9,6 +9,12 @@ r.settings.render_mode = mode
 r.settings.bounces = int(sys.argv[2]) if len(sys.argv) > 2 else 1
 r.settings.max_samples = 1 << 30
 r.bind_uniforms()
+r.render(frames=2, rebind=False); r.finish()
+import time
+t0 = time.perf_counter()
+while time.perf_counter() - t0 < 0.15:          # bring the device to its sustained clock
+    r.render(frames=16, rebind=False, in_flight=16); r.finish()
+r.restart_rendering(); r.bind_uniforms()
 r.render(frames=2, rebind=False); r.finish(); r.reset_counters()
 r.render(frames=32, rebind=False, in_flight=16); r.finish()
 c = r.counters()
