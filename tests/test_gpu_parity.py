@@ -126,7 +126,7 @@ def test_golden_stochastic_modes(oracle, name, layout):
 
 
 # ---- row N3: environment-map lighting (environment.ts, envSetup.frag, environment.glsl) ----------
-@pytest.mark.parametrize("mode,bounces", [("default", 1), ("default", 3), ("no_dda", 2), ("raymarch", 1)])
+@pytest.mark.parametrize("mode,bounces", [("default", 1), ("default", 3), ("no_dda", 2), ("raymarch", 1), ("default", 0)])
 def test_repacked_path_kernel_is_bit_identical(oracle, mode, bounces, monkeypatch):
     """vx_paths.hpp (VX_PATHS_KERNEL=packed): the collided paths of a 16x16-pixel workgroup are re-packed through LDS
     between the primary and the shadow segments.  A path record carries its pixel's xoshiro state, so every pixel
@@ -158,6 +158,21 @@ def test_repacked_path_kernel_is_bit_identical(oracle, mode, bounces, monkeypatc
         a, b = res[("generic", layout)], res[("packed", layout)]
         assert np.array_equal(a[0], b[0]) and a[1:] == b[1:], (mode, layout)
         assert a[1] > 0 and np.isfinite(a[0]).all()
+
+
+def test_transfer_function_must_be_finite():
+    """vx_upload_transfer refuses Inf / NaN entries (the DVR composite is straight-line: 0 * Inf would reach lanes that
+    never sampled the entry); the previous table stays in use"""
+    from volxel_amd import Volxel3DRenderer, VolxelError
+    r = Volxel3DRenderer(64, 64)
+    tf = np.ones((16, 4), dtype=np.float32)
+    r.change_transfer_func(tf, 16)
+    for bad in (np.inf, -np.inf, np.nan):
+        t2 = tf.copy()
+        t2[5, 2] = bad
+        with pytest.raises(VolxelError, match="not finite"):
+            r.change_transfer_func(t2, 16)
+    r.close()
 
 
 def test_importance_pyramid_is_bit_identical(oracle):

@@ -3,6 +3,7 @@
 
 #include <algorithm>
 #include <chrono>
+#include <cmath>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
@@ -469,7 +470,9 @@ static void launch_paths(VxContext* c, const MultiOut& mo, float weight, dim3 gr
 
 static void launch_generic_mode(VxContext* c, const MultiOut& mo, float weight, dim3 grid, hipStream_t stream) {
   size_t lds = c->tf_len <= TF_LDS_MAX ? (size_t)c->tf_len * sizeof(float4) : 0;
-  if (c->paths_variant != 0 && !c->params.debug_hits && c->params.render_mode <= VX_MODE_RAYMARCH) {
+  // (bounces < 1: fragment.frag:86-101 still traces the primary segment and one light sample before it tests the
+  // count; render_paths loops on `n_paths < bounces` and would leave the slab unwritten -- render_generic serves it)
+  if (c->paths_variant != 0 && !c->params.debug_hits && c->params.render_mode <= VX_MODE_RAYMARCH && c->params.bounces >= 1) {
     switch (c->params.render_mode) {
       case VX_MODE_DEFAULT: launch_paths<VX_MODE_DEFAULT>(c, mo, weight, grid, lds, stream); break;
       case VX_MODE_NO_DDA: launch_paths<VX_MODE_NO_DDA>(c, mo, weight, grid, lds, stream); break;
@@ -761,11 +764,14 @@ int vx_upload_volume(VxContext* c, const uint32_t* indirection, const uint32_t i
   };
   void *d_ind = nullptr, *d_range = nullptr, *d_atlas = nullptr, *d_mip[3] = {nullptr, nullptr, nullptr};
   int rc;
-  if ((rc = alloc(nb * 4, &d_ind)) || (rc = alloc(nb * 4, &d_range)) || (rc = alloc(atlas_bytes, &d_atlas))) return rc;
+  // the atlas allocation is never empty: a tap that points outside the pruned atlas reads byte 0 and selects 0
+  // (lookup_density_brick is straight-line code)
+  if ((rc = alloc(nb * 4, &d_ind)) || (rc = alloc(nb * 4, &d_range)) || (rc = alloc(atlas_bytes ? atlas_bytes : 16, &d_atlas))) { free_volume(c); return rc; }
+  if (!atlas_bytes) VX_HIP(c, hipMemsetAsync(d_atlas, 0, 16, c->stream));
   size_t mip_n[3];
   for (int k = 0; k < 3; ++k) {
     mip_n[k] = (size_t)mip_size[k][0] * mip_size[k][1] * mip_size[k][2];
-    if ((rc = alloc(mip_n[k] * 4, &d_mip[k]))) return rc;
+    if ((rc = alloc(mip_n[k] * 4, &d_mip[k]))) { free_volume(c); return rc; }
     c->dv.mips[k] = (const uint32_t*)d_mip[k];
     for (int i = 0; i < 3; ++i) c->dv.mip_size[k][i] = mip_size[k][i];
   }
@@ -781,16 +787,19 @@ int vx_upload_volume(VxContext* c, const uint32_t* indirection, const uint32_t i
   c->skip_dirty = true;
   c->order_builds_left = 2;
   uint32_t n_layers = 0;
-  if ((rc = alloc_layout(c, n_layers))) return rc;
+  if ((rc = alloc_layout(c, n_layers))) { free_volume(c); return rc; }
   if (!c->aux_stream) VX_HIP(c, hipStreamCreateWithFlags(&c->aux_stream, hipStreamNonBlocking));
 
   // ---- copies: metadata first, then the atlas in chunks of whole 8-slice layers from pinned memory;
   //      the layout layers whose bricks are complete are built on the aux stream behind each chunk
+  // Every failure from here on goes through ONE exit (below): both streams are synchronised before the pinned
+  // ranges are unregistered and the partial volume is freed -- an early return would unpin pages an earlier
+  // asynchronous copy may still be reading.
   PinnedRange pin_atlas(atlas, atlas_bytes), pin_ind(indirection, nb * 4), pin_range(range, nb * 4);
-  VX_HIP(c, hipMemcpyAsync(d_ind, indirection, nb * 4, hipMemcpyHostToDevice, c->stream));
-  VX_HIP(c, hipMemcpyAsync(d_range, range, nb * 4, hipMemcpyHostToDevice, c->stream));
-  for (int k = 0; k < 3; ++k)
-    if (mip_n[k]) VX_HIP(c, hipMemcpyAsync(d_mip[k], mip_data[k], mip_n[k] * 4, hipMemcpyHostToDevice, c->stream));
+  hipError_t le = hipMemcpyAsync(d_ind, indirection, nb * 4, hipMemcpyHostToDevice, c->stream);
+  if (le == hipSuccess) le = hipMemcpyAsync(d_range, range, nb * 4, hipMemcpyHostToDevice, c->stream);
+  for (int k = 0; k < 3 && le == hipSuccess; ++k)
+    if (mip_n[k]) le = hipMemcpyAsync(d_mip[k], mip_data[k], mip_n[k] * 4, hipMemcpyHostToDevice, c->stream);
   const uint32_t atlas_layers = atlas_size[2] / 8u;
   const size_t layer_bytes = (size_t)atlas_size[0] * atlas_size[1] * 8u;
   const uint32_t chunk_layers = layer_bytes ? (uint32_t)std::max<size_t>(1, (16u << 20) / layer_bytes) : 1u;
@@ -806,7 +815,6 @@ int vx_upload_volume(VxContext* c, const uint32_t* indirection, const uint32_t i
     }
     return z;
   };
-  hipError_t le = hipSuccess;
   for (uint32_t l0 = 0; l0 < atlas_layers && le == hipSuccess; l0 += chunk_layers) {
     uint32_t l1 = l0 + chunk_layers < atlas_layers ? l0 + chunk_layers : atlas_layers;
     le = hipMemcpyAsync((char*)d_atlas + l0 * layer_bytes, atlas + l0 * layer_bytes, (l1 - l0) * layer_bytes,
@@ -895,6 +903,11 @@ int vx_upload_transfer(VxContext* c, const float* rgba, uint32_t length) {
   if (!c) return VX_ERR_INVALID;
   VX_DEV(c);
   if (!rgba || length == 0) VX_FAIL(c, VX_ERR_INVALID, "vx_upload_transfer: empty transfer function");
+  // the DVR composite runs straight-line for every lane of a wave step (a lane that does not contribute adds
+  // dT * rgb with dT = +0): an Inf / NaN entry would turn that 0 into NaN for lanes that never sampled it
+  for (size_t i = 0; i < (size_t)length * 4; ++i)
+    if (!std::isfinite(rgba[i]))
+      VX_FAIL(c, VX_ERR_INVALID, "vx_upload_transfer: entry %zu component %zu is not finite", i / 4, i % 4);
   VX_HIP(c, hipStreamSynchronize(c->stream));
   if (c->tf) (void)hipFree(c->tf);
   c->tf = nullptr;

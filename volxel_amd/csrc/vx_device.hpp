@@ -113,7 +113,9 @@ VXD uint32_t mad24_s(uint32_t a, uint32_t b_uniform, uint32_t c) {
   asm("v_mad_u32_u24 %0, %1, %2, %3" : "=v"(r) : "v"(a), "s"(b_uniform), "v"(c));
   return r;
 }
-// clamp to [0, hi_uniform] in one instruction, the wave-uniform bound straight from its SGPR
+// clamp to [0, hi_uniform] in one instruction, the wave-uniform bound straight from its SGPR.  hi_uniform MUST be
+// wave uniform (a kernel argument or derived from one): an "s" operand fed a divergent value is silently read from
+// the first active lane.  Every call site passes a function of DevVolume / tf_len.
 VXD int clamp0_i32(int x, int hi_uniform) {
   int r;
   asm("v_med3_i32 %0, %1, 0, %2" : "=v"(r) : "v"(x), "s"(hi_uniform));
@@ -210,35 +212,45 @@ VXD float unorm8(uint32_t c) {
   return fma_(e, r, q);
 }
 
-// A4: lookup_density_brick, common.glsl:35-43; out-of-range taps are 0
+// A4: lookup_density_brick, common.glsl:35-43; out-of-range taps are 0.
+// Straight-line: the coordinates are clamped into the grid, every lane runs the range -> pointer -> atlas chain,
+// and the bounds tests select the result.  (The first form returned early per tap; eight -- for the Phong gradient
+// 56 -- nested divergent ifs per sample serialise the three dependent loads of every tap and gave the register
+// allocator 112 join blocks per loop body to place spill code in: DESIGN.md section 5.3.)
 VXD float lookup_density_brick(const DevVolume& v, int x, int y, int z) {
-  if ((uint32_t)x >= v.extent[0] || (uint32_t)y >= v.extent[1] || (uint32_t)z >= v.extent[2])
-    return 0.0f;
-  uint32_t bx = (uint32_t)x >> 3, by = (uint32_t)y >> 3, bz = (uint32_t)z >> 3;
-  uint32_t bi = (bz * v.bc[1] + by) * v.bc[0] + bx;
-  uint32_t rg = v.range[bi];
-  float mn = half_bits_to_float(rg >> 16), mx = half_bits_to_float(rg & 0xffffu);
-  uint32_t ptr = v.indirection[bi];
-  uint32_t ax = ((ptr & 1023u) << 3) + ((uint32_t)x & 7u);
-  uint32_t ay = (((ptr >> 10) & 1023u) << 3) + ((uint32_t)y & 7u);
-  uint32_t az = (((ptr >> 20) & 1023u) << 3) + ((uint32_t)z & 7u);
-  float un = 0.0f;  // WebGL2 robust texelFetch: outside the (pruned) atlas -> 0
-  if (az < v.atlas_size[2])
-    un = unorm8(v.atlas[((size_t)az * v.atlas_size[1] + ay) * v.atlas_size[0] + ax]);
-  return fma_(un, mx - mn, mn);
+  const bool in = (uint32_t)x < v.extent[0] && (uint32_t)y < v.extent[1] && (uint32_t)z < v.extent[2];
+  const uint32_t ux = (uint32_t)clamp0_i32(x, (int)v.extent[0] - 1), uy = (uint32_t)clamp0_i32(y, (int)v.extent[1] - 1),
+                 uz = (uint32_t)clamp0_i32(z, (int)v.extent[2] - 1);
+  const uint32_t bi = ((uz >> 3) * v.bc[1] + (uy >> 3)) * v.bc[0] + (ux >> 3);
+  const uint32_t rg = v.range[bi];
+  const float mn = half_bits_to_float(rg >> 16), mx = half_bits_to_float(rg & 0xffffu);
+  const uint32_t ptr = v.indirection[bi];
+  const uint32_t ax = ((ptr & 1023u) << 3) + (ux & 7u);
+  const uint32_t ay = (((ptr >> 10) & 1023u) << 3) + (uy & 7u);
+  const uint32_t az = (((ptr >> 20) & 1023u) << 3) + (uz & 7u);
+  // WebGL2 robust texelFetch: outside the (pruned) atlas -> 0 (a constant brick keeps pointer 0: quirk Q6)
+  // (such a lane reads byte 0: the atlas allocation is never empty, vx_upload_volume)
+  const bool inz = az < v.atlas_size[2];
+  const size_t ao = ((size_t)az * v.atlas_size[1] + ay) * v.atlas_size[0] + ax;
+  float un = unorm8(v.atlas[inz ? ao : (size_t)0]);
+  un = inz ? un : 0.0f;
+  const float r = fma_(un, mx - mn, mn);
+  return in ? r : 0.0f;
 }
 
 VXD float gl_mix(float x, float y, float a) { return fma_(y, a, x * (1.0f - a)); }
 
 enum { LAYOUT_REF = 0, LAYOUT_CQ = 1, LAYOUT_BF = 2 };
 
-// decoded voxel from the brickf32 layout; out-of-range taps are 0
+// decoded voxel from the brickf32 layout; out-of-range taps are 0; straight-line as above
 VXD float bf_voxel(const DevVolume& v, int x, int y, int z) {
-  if ((uint32_t)x >= v.extent[0] || (uint32_t)y >= v.extent[1] || (uint32_t)z >= v.extent[2])
-    return 0.0f;
-  uint32_t b = (((uint32_t)z >> 3) * v.bc[1] + ((uint32_t)y >> 3)) * v.bc[0] + ((uint32_t)x >> 3);
-  uint32_t l = (((uint32_t)z & 7u) << 6) | (((uint32_t)y & 7u) << 3) | ((uint32_t)x & 7u);
-  return v.bf[(size_t)b * 512u + l];
+  const bool in = (uint32_t)x < v.extent[0] && (uint32_t)y < v.extent[1] && (uint32_t)z < v.extent[2];
+  const uint32_t ux = (uint32_t)clamp0_i32(x, (int)v.extent[0] - 1), uy = (uint32_t)clamp0_i32(y, (int)v.extent[1] - 1),
+                 uz = (uint32_t)clamp0_i32(z, (int)v.extent[2] - 1);
+  const uint32_t b = ((uz >> 3) * v.bc[1] + (uy >> 3)) * v.bc[0] + (ux >> 3);
+  const uint32_t l = ((uz & 7u) << 6) | ((uy & 7u) << 3) | (ux & 7u);
+  const float r = v.bf[(size_t)b * 512u + l];
+  return in ? r : 0.0f;
 }
 
 // A4 through the device layouts: the decoded value of voxel (x,y,z) is the .x tap of cellquad cell
@@ -247,11 +259,13 @@ VXD float bf_voxel(const DevVolume& v, int x, int y, int z) {
 template <int LAYOUT>
 VXD float lookup_density_nearest(const DevVolume& v, int x, int y, int z) {
   if (LAYOUT == LAYOUT_CQ) {
-    if ((uint32_t)x >= v.extent[0] || (uint32_t)y >= v.extent[1] || (uint32_t)z >= v.extent[2]) return 0.0f;
-    uint32_t cx = (uint32_t)x + 1u, cy = (uint32_t)y + 1u, cz = (uint32_t)z + 1u;
-    uint32_t b = ((cz >> 3) * v.cq_bc[1] + (cy >> 3)) * v.cq_bc[0] + (cx >> 3);
-    size_t o = (size_t)b * CQ_BRICK_QUADS + cq_cell(cx & 7u, cy & 7u, cz & 7u);
-    return reinterpret_cast<const float*>(v.cq + o)[0];
+    const bool in = (uint32_t)x < v.extent[0] && (uint32_t)y < v.extent[1] && (uint32_t)z < v.extent[2];
+    const uint32_t cx = (uint32_t)clamp0_i32(x, (int)v.extent[0] - 1) + 1u, cy = (uint32_t)clamp0_i32(y, (int)v.extent[1] - 1) + 1u,
+                   cz = (uint32_t)clamp0_i32(z, (int)v.extent[2] - 1) + 1u;
+    const uint32_t b = ((cz >> 3) * v.cq_bc[1] + (cy >> 3)) * v.cq_bc[0] + (cx >> 3);
+    const size_t o = (size_t)b * CQ_BRICK_QUADS + cq_cell(cx & 7u, cy & 7u, cz & 7u);
+    const float r = reinterpret_cast<const float*>(v.cq + o)[0];
+    return in ? r : 0.0f;
   } else if (LAYOUT == LAYOUT_BF) {
     return bf_voxel(v, x, y, z);
   }
@@ -265,14 +279,17 @@ VXD float trilinear_cell(const DevVolume& v, float density_scale, int ix, int iy
   if (LAYOUT == LAYOUT_CQ) {
     // cell (ix,iy,iz) lives in apron brick (i+1)>>3 at local (i+1)&7; both z slices of the
     // xy-quad are one 16-byte load each, already decoded with each tap's own brick range
-    uint32_t cx = (uint32_t)(ix + 1), cy = (uint32_t)(iy + 1), cz = (uint32_t)(iz + 1);
-    if (cx > v.extent[0] + 7u || cy > v.extent[1] + 7u || cz > v.extent[2] + 7u) return 0.0f * density_scale;
-    uint32_t b = ((cz >> 3) * v.cq_bc[1] + (cy >> 3)) * v.cq_bc[0] + (cx >> 3);
-    size_t o = (size_t)b * CQ_BRICK_QUADS + cq_cell(cx & 7u, cy & 7u, cz & 7u);
-    float4 q0 = v.cq[o];
-    float4 q1 = v.cq[o + cq_next_slice(cz)];
-    v000 = q0.x; v100 = q0.y; v010 = q0.z; v110 = q0.w;
-    v001 = q1.x; v101 = q1.y; v011 = q1.z; v111 = q1.w;
+    // a cell outside the apron lattice [-1, extent + 6] has eight zero taps: the index is clamped into the lattice
+    // and the quads selected to 0 (straight-line; mix of zeros = +0, times the scale as before)
+    const int mxx = (int)v.extent[0] + 7, mxy = (int)v.extent[1] + 7, mxz = (int)v.extent[2] + 7;
+    const bool in = (uint32_t)(ix + 1) <= (uint32_t)mxx && (uint32_t)(iy + 1) <= (uint32_t)mxy && (uint32_t)(iz + 1) <= (uint32_t)mxz;
+    const uint32_t cx = (uint32_t)clamp0_i32(ix + 1, mxx), cy = (uint32_t)clamp0_i32(iy + 1, mxy), cz = (uint32_t)clamp0_i32(iz + 1, mxz);
+    const uint32_t b = ((cz >> 3) * v.cq_bc[1] + (cy >> 3)) * v.cq_bc[0] + (cx >> 3);
+    const size_t o = (size_t)b * CQ_BRICK_QUADS + cq_cell(cx & 7u, cy & 7u, cz & 7u);
+    const float4 q0 = v.cq[o];
+    const float4 q1 = v.cq[o + cq_next_slice(cz)];
+    v000 = in ? q0.x : 0.0f; v100 = in ? q0.y : 0.0f; v010 = in ? q0.z : 0.0f; v110 = in ? q0.w : 0.0f;
+    v001 = in ? q1.x : 0.0f; v101 = in ? q1.y : 0.0f; v011 = in ? q1.z : 0.0f; v111 = in ? q1.w : 0.0f;
   } else if (LAYOUT == LAYOUT_BF) {
     v000 = bf_voxel(v, ix, iy, iz);
     v100 = bf_voxel(v, ix + 1, iy, iz);

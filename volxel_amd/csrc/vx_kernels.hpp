@@ -162,7 +162,7 @@ VXD void multi_slot(uint32_t p, uint32_t count, uint32_t& fslot, uint32_t& bslot
 // dvr_phong has its tuned kernel (vx_dvr_lds.hpp); the generic form only serves the reference / cellquad layouts.
 // Forced to 8 waves it spilled 49-57 registers and the REFERENCE-layout build then produced wrong pixels
 // (tests/test_gpu_parity.py::test_golden_deterministic[noise32_phong-0]: 6e-2 off, fine at 4): not forced.
-#define VX_W_PHONG 4
+#define VX_W_PHONG 8
 #endif
 constexpr int generic_min_waves(int mode) {
   return mode == VX_MODE_DEFAULT ? VX_W_DEFAULT : mode == VX_MODE_DVR_PHONG ? VX_W_PHONG

@@ -14,7 +14,11 @@ export declare class Camera {
   pos: number[]; view: number[];
   /** [build] null: the reference's perspective camera (scene.ts:65-72); a number: orthographic, image spans +-orthoHalfHeight world units vertically */
   orthoHalfHeight: number | null;
+  yaw: number; pitch: number;
   constructor(distance?: number); viewMatrix(): number[]; projMatrix(aspect: number, fov?: number): number[];
+  /** scene.ts:15-52 */
+  rotateAroundView(by: [number, number]): void; zoom(by: number): boolean;
+  translateOnPlane(by: [number, number]): void; translate(by: [number, number, number]): void;
 }
 export declare class Environment {          // representation/environment.ts; row 0 of `floats` = top
   constructor(floats: Float32Array, width: number, height: number, strength?: number);
@@ -29,6 +33,17 @@ export declare class Volxel3DDicomRenderer {
   settings: Record<string, any>; camera: Camera; envStrength: number; frameIndex: number;
   renderMode: keyof typeof VolxelRenderMode;
   restartFromFiles(files: (string | Uint8Array)[], threads?: number): void;
+  /** viewer.ts:977-1040.  ZIP (stored / deflate) and Radiance RGBE are decoded by the host; URLs are paths or file:// URLs
+   *  (no fetch in this Node); OpenEXR bytes are refused with a message naming setupEnv(). */
+  restartFromZip(zip: string | Uint8Array, threads?: number): void;
+  restartFromZipUrl(url: string, threads?: number): void;
+  restartFromURLs(urls: string[], threads?: number): void;
+  loadEnv(bytes: Uint8Array): void;
+  loadEnvFromUrl(url: string): void;
+  /** viewer.ts:443-449,543-551,789-795: the light follows the camera when settings.syncLightDir is on */
+  maybeSyncLight(): void;
+  rotateCamera(by: [number, number]): void;
+  syncLightDir: boolean;
   setupEnv(env: { width: number; height: number; floats: Float32Array }): void;
   /** restartFromFiles for slices already read into memory */
   restartFromBytes(files: Uint8Array[], threads?: number): void;
@@ -52,3 +67,7 @@ export declare class Volxel3DDicomRenderer {
   resetCounters(): void;
   dispose(): void;
 }
+/** viewer.ts:1455-1462: keeps the worker factory, returns the element-name -> class table ("volxel-3d-viewer") */
+export declare function registerVolxelComponents(worker?: () => unknown): Record<string, typeof Volxel3DDicomRenderer>;
+export declare function readZipSlices(zip: Uint8Array): Uint8Array[];
+export declare function decodeEnvironment(bytes: Uint8Array): { floats: Float32Array; width: number; height: number };

@@ -125,9 +125,46 @@ function generateTransferFunction(colors, generatedSteps = 128) {
   return { data: new Float32Array(out.flat()), length: generatedSteps };
 }
 
+// math.gl Quaternion / Vector3 pieces used by the orbit camera (gl-matrix quat.setAxisAngle, quat.multiply, vec3.transformQuat)
+const Q = {
+  axis: (a, rad) => { const s = Math.sin(rad * 0.5); return [a[0] * s, a[1] * s, a[2] * s, Math.cos(rad * 0.5)]; },
+  mul: (a, b) => [a[0] * b[3] + a[3] * b[0] + a[1] * b[2] - a[2] * b[1], a[1] * b[3] + a[3] * b[1] + a[2] * b[0] - a[0] * b[2],
+    a[2] * b[3] + a[3] * b[2] + a[0] * b[1] - a[1] * b[0], a[3] * b[3] - a[0] * b[0] - a[1] * b[1] - a[2] * b[2]],
+  rot: (v, q) => {
+    const cross = (a, b) => [a[1] * b[2] - a[2] * b[1], a[2] * b[0] - a[0] * b[2], a[0] * b[1] - a[1] * b[0]];
+    const uv = cross(q, v), uuv = cross(q, uv);
+    return [0, 1, 2].map(i => v[i] + 2 * q[3] * uv[i] + 2 * uuv[i]);
+  },
+};
+const V = {
+  sub: (a, b) => a.map((x, i) => x - b[i]), add: (a, b) => a.map((x, i) => x + b[i]), scale: (a, s) => a.map(x => x * s),
+  len: a => Math.sqrt(a[0] * a[0] + a[1] * a[1] + a[2] * a[2]), norm: a => V.scale(a, 1 / V.len(a)),
+  cross: (a, b) => [a[1] * b[2] - a[2] * b[1], a[2] * b[0] - a[0] * b[2], a[0] * b[1] - a[1] * b[0]],
+};
+
 class Camera { // representation/scene.ts
   // orthoHalfHeight ([build], BASELINE config 1): null = the reference's perspective camera
-  constructor(distance = 1) { this.view = [0, 0, 0]; this.pos = [0, 0, -distance]; this.orthoHalfHeight = null; }
+  constructor(distance = 1) { this.view = [0, 0, 0]; this.pos = [0, 0, -distance]; this.orthoHalfHeight = null; this.yaw = 0; this.pitch = 0; }
+  rotateAroundView(by) { // scene.ts:15-33
+    this.yaw += -by[0]; this.pitch += by[1];
+    const maxPitch = Math.PI / 2 - 0.01;
+    this.pitch = Math.min(Math.max(this.pitch, -maxPitch), maxPitch);
+    const qYaw = Q.axis([0, 1, 0], this.yaw);
+    const right = V.norm(Q.rot([1, 0, 0], qYaw));
+    const orientation = Q.mul(Q.axis(right, this.pitch), qYaw);
+    this.pos = V.add(V.scale(Q.rot([0, 0, -1], orientation), V.len(V.sub(this.pos, this.view))), this.view);
+  }
+  zoom(by) { // scene.ts:35-40
+    const dir = V.sub(this.pos, this.view), n = V.len(dir);
+    if (n * by <= 0.1 || n * by >= 10) return false;
+    this.pos = V.add(V.scale(dir, by), this.view);
+    return true;
+  }
+  translateOnPlane(by) { // scene.ts:42-47
+    const dir = V.sub(this.pos, this.view), right = V.norm(V.cross(dir, [0, 1, 0])), localUp = V.norm(V.cross(dir, right));
+    this.translate(V.add(V.scale(right, by[0] * 5), V.scale(localUp, -by[1] * 5)));
+  }
+  translate(by) { this.pos = V.add(this.pos, by); this.view = V.add(this.view, by); } // scene.ts:49-52
   viewMatrix() { return M.lookAt(this.pos, this.view, [0, 1, 0]); }
   projMatrix(aspect, fov = Math.PI / 3) {
     if (this.orthoHalfHeight !== null) {
@@ -155,6 +192,87 @@ class Environment {
     }
     return new Environment(d, width, height);
   }
+}
+
+// ---- container I/O behind the load methods (not on the hot path; what Node's own zlib / fs can decode) ------------
+/** zip.rs:36-115: files in archive order, at most one directory entry, every later file directly inside it */
+function readZipSlices(buf) {
+  const zlib = require('zlib');
+  const fail = (kind, msg) => { throw new Error(`${kind}: ${msg === undefined ? 'No Message Specified' : msg}`); };
+  let eocd = -1;
+  for (let i = buf.length - 22; i >= Math.max(0, buf.length - 65557); --i) if (buf.readUInt32LE(i) === 0x06054b50) { eocd = i; break; }
+  if (eocd < 0) fail('ExtractFailed', 'invalid Zip archive: Could not find central directory end');
+  const total = buf.readUInt16LE(eocd + 10);
+  let p = buf.readUInt32LE(eocd + 16);
+  if (total < 1) fail('NoFiles');
+  let directory = null;
+  const out = [];
+  for (let k = 0; k < total; ++k) {
+    if (buf.readUInt32LE(p) !== 0x02014b50) fail('ExtractFailed', 'invalid central directory entry');
+    const method = buf.readUInt16LE(p + 10), csize = buf.readUInt32LE(p + 20), nlen = buf.readUInt16LE(p + 28),
+      xlen = buf.readUInt16LE(p + 30), clen = buf.readUInt16LE(p + 32), lho = buf.readUInt32LE(p + 42);
+    const name = buf.toString('utf8', p + 46, p + 46 + nlen);
+    p += 46 + nlen + xlen + clen;
+    const norm = require('path').posix.normalize(name);
+    if (name.startsWith('/') || norm.startsWith('..')) fail('ExtractFailed', 'No enclosed name was able to be found');
+    if (name.endsWith('/')) {
+      if (directory !== null) fail('MoreThanOneFolder');
+      directory = norm.replace(/\/$/, '');
+      continue;
+    }
+    if (directory !== null && require('path').posix.dirname(norm) !== directory) fail('MoreThanOneFolder');
+    const dataAt = lho + 30 + buf.readUInt16LE(lho + 26) + buf.readUInt16LE(lho + 28);
+    const raw = buf.slice(dataAt, dataAt + csize);
+    if (method === 0) out.push(new Uint8Array(raw));
+    else if (method === 8) out.push(new Uint8Array(zlib.inflateRawSync(raw)));
+    else fail('ExtractFailed', `unsupported compression method ${method}`);
+  }
+  if (!out.length) fail('NoFiles', 'No dicom data collected');
+  return out;
+}
+/** worker.ts:115-126 fetch(url) + exportResponseBytes: a path or a file:// URL (this Node has no fetch, the machines no network) */
+function fetchBytes(url) {
+  const fs = require('fs');
+  if (/^file:\/\//.test(url)) return fs.readFileSync(new (require('url').URL)(url));
+  if (/^[a-z][a-z0-9+.-]*:\/\//i.test(url)) throw new Error(`fetch is not available in this host: ${url} (read the bytes and call the *Bytes / loadEnv method)`);
+  return fs.readFileSync(url);
+}
+/** hdr.rs:23-36: encoded environment map -> { floats, width, height } with row 0 = top.  Radiance RGBE only. */
+function decodeEnvironment(b) {
+  if (b.length >= 4 && b.readUInt32LE(0) === 0x01312f76) throw new Error("OpenEXR decode is outside this build's scope (hdr.rs uses the `image` crate's exr decoder): decode the map elsewhere and pass {width, height, floats} to setupEnv()");
+  const head = b.toString('latin1', 0, 10);
+  if (!head.startsWith('#?RADIANCE') && !head.startsWith('#?RGBE')) throw new Error('unrecognised environment map format (expected Radiance RGBE; decoded floats go to setupEnv())');
+  let pos = b.indexOf('\n\n') + 2;
+  if (!b.toString('latin1', 0, pos).includes('FORMAT=32-bit_rle_rgbe')) throw new Error('Radiance map: only FORMAT=32-bit_rle_rgbe is supported');
+  const eol = b.indexOf('\n', pos), dims = b.toString('latin1', pos, eol).trim().split(/\s+/);
+  if (dims.length !== 4 || dims[0] !== '-Y' || dims[2] !== '+X') throw new Error('Radiance map: only the standard -Y h +X w orientation is supported');
+  const h = parseInt(dims[1], 10), w = parseInt(dims[3], 10);
+  let p = eol + 1;
+  const px = new Uint8Array(w * h * 4);
+  for (let y = 0; y < h; ++y) {
+    if (w >= 8 && w < 32768 && b[p] === 2 && b[p + 1] === 2 && ((b[p + 2] << 8) | b[p + 3]) === w) {
+      p += 4;
+      for (let ch = 0; ch < 4; ++ch) for (let x = 0; x < w;) {
+        let n = b[p++];
+        if (n > 128) { n -= 128; const v = b[p++]; for (let k = 0; k < n; ++k) px[(y * w + x + k) * 4 + ch] = v; } else { for (let k = 0; k < n; ++k) px[(y * w + x + k) * 4 + ch] = b[p++]; }
+        x += n;
+      }
+    } else { for (let k = 0; k < 4 * w; ++k) px[y * w * 4 + k] = b[p++]; }
+  }
+  const floats = new Float32Array(w * h * 4);
+  for (let i = 0; i < w * h; ++i) {
+    const e = px[4 * i + 3], s = e > 0 ? Math.pow(2, e - 136) : 0;
+    floats[4 * i] = Math.fround(px[4 * i] * s); floats[4 * i + 1] = Math.fround(px[4 * i + 1] * s); floats[4 * i + 2] = Math.fround(px[4 * i + 2] * s); floats[4 * i + 3] = 1;
+  }
+  return { floats, width: w, height: h };
+}
+
+let workerFactory = null;
+/** registerVolxelComponents (viewer.ts:1455-1462): keeps the worker factory and names the component classes.  The four
+ *  widget elements are browser UI without a counterpart here; the renderer calls the native preprocessor in-process. */
+function registerVolxelComponents(worker) {
+  workerFactory = worker || null;
+  return { 'volxel-3d-viewer': Volxel3DDicomRenderer };
 }
 
 class Volxel3DDicomRenderer {
@@ -203,6 +321,30 @@ class Volxel3DDicomRenderer {
     const fs = require('fs');
     this.restartFromBytes(files.map(f => (typeof f === 'string' ? new Uint8Array(fs.readFileSync(f)) : f)), threads);
   }
+  /** restartFromZip (viewer.ts:977-989): a ZIP of DICOM slices (Buffer / Uint8Array / path), folder rule of zip.rs:54-70 */
+  restartFromZip(zip, threads = 0) {
+    const fs = require('fs');
+    this.restartFromBytes(readZipSlices(typeof zip === 'string' ? fs.readFileSync(zip) : Buffer.from(zip.buffer || zip, zip.byteOffset || 0, zip.byteLength)), threads);
+  }
+  /** restartFromZipUrl (viewer.ts:991-1003, worker.ts:115-118) */
+  restartFromZipUrl(url, threads = 0) { this.restartFromZip(fetchBytes(url), threads); }
+  /** restartFromURLs (viewer.ts:1005-1017, worker.ts:120-123): one slice per URL, in the order given */
+  restartFromURLs(urls, threads = 0) { this.restartFromBytes(urls.map(u => new Uint8Array(fetchBytes(u))), threads); }
+  /** loadEnv (viewer.ts:1019-1033, worker.ts:77-90, hdr.rs:23-36): Radiance RGBE is decoded, OpenEXR is refused */
+  loadEnv(bytes) { this.setupEnv(decodeEnvironment(Buffer.from(bytes.buffer || bytes, bytes.byteOffset || 0, bytes.byteLength))); }
+  /** loadEnvFromUrl (viewer.ts:1035-1040) */
+  loadEnvFromUrl(url) { this.loadEnv(fetchBytes(url)); }
+  /** maybeSyncLight (viewer.ts:789-795): lightDir = -(view - pos), normalised by the direction widget it is assigned to
+   *  (cubeDirection.ts:177-206).  Called after a camera rotation and by the backlight toggle -- not by restoreSettings,
+   *  exactly as in the reference. */
+  maybeSyncLight() {
+    if (!this.settings.syncLightDir) return;
+    const d = V.sub(this.camera.pos, this.camera.view), n = V.len(d);
+    if (n > 0) this.settings.lightDir = V.scale(d, 1 / n);
+  }
+  rotateCamera(by) { this.camera.rotateAroundView(by); this.maybeSyncLight(); this.restartRendering(); } // viewer.ts:443-449
+  get syncLightDir() { return this.settings.syncLightDir; }
+  set syncLightDir(on) { this.settings.syncLightDir = !!on; this.maybeSyncLight(); this.restartRendering(); } // viewer.ts:543-551
   /** setupEnv (viewer.ts:1073-1078): { width, height, floats } with row 0 = top */
   setupEnv(env) { this.setEnvironment(new Environment(env.floats, env.width, env.height)); }
   /** the same once the files are in memory: one Uint8Array per slice (worker.ts:101-104) */
@@ -386,4 +528,5 @@ class Volxel3DDicomRenderer {
   resetCounters() { native.resetCounters(this.ctx); }
 }
 
-module.exports = { Volxel3DDicomRenderer, Environment, VolxelRenderMode: RenderMode, generateTransferFunction, Camera, native };
+module.exports = { Volxel3DDicomRenderer, Environment, VolxelRenderMode: RenderMode, generateTransferFunction, Camera, native,
+  registerVolxelComponents, readZipSlices, decodeEnvironment, fetchBytes, getWorkerFactory: () => workerFactory };

@@ -107,6 +107,22 @@ def compute_params(settings: ViewerSettings, camera: Camera, volume: Volume, den
     return p
 
 
+_worker_factory = None
+COMPONENTS = {}
+
+
+def register_volxel_components(worker_factory=None):
+    """registerVolxelComponents (viewer.ts:1455-1462): remembers the worker factory and registers the component
+    classes under the reference's element names.  The four widget elements (slider, histogram viewer, cube direction,
+    colour ramp) are browser UI and have no counterpart here; `volxel-3d-viewer` maps to the renderer class.  The
+    factory is kept for hosts that run the preprocessor elsewhere: the renderer itself calls the native preprocessor
+    in-process."""
+    global _worker_factory
+    _worker_factory = worker_factory
+    COMPONENTS["volxel-3d-viewer"] = Volxel3DRenderer
+    return COMPONENTS
+
+
 class Volxel3DRenderer:
     """Headless counterpart of the `<volxel-3d-viewer>` element's render core."""
 
@@ -186,6 +202,71 @@ class Volxel3DRenderer:
                 with open(f, "rb") as fh:
                     blobs.append(fh.read())
         self.setup_from_grid(read_dicoms_to_grid(blobs, n_threads))
+
+    # -- viewer.ts:977-1017: the other load methods.  The reference posts the bytes to its worker, which decodes
+    #    them (worker.ts:60-76,105-126); here the host decodes what the Python standard library can (containers.py)
+    def restart_from_zip(self, zip_file, n_threads: int = 0):
+        """restartFromZip (viewer.ts:977-989): a ZIP of DICOM slices as bytes or a path; folder rule of zip.rs:54-70"""
+        from .containers import read_zip_slices
+        from .preprocessor import read_dicoms_to_grid
+        if not isinstance(zip_file, (bytes, bytearray, memoryview)):
+            with open(zip_file, "rb") as fh:
+                zip_file = fh.read()
+        self.setup_from_grid(read_dicoms_to_grid(read_zip_slices(zip_file), n_threads))
+
+    def restart_from_zip_url(self, url: str, n_threads: int = 0):
+        """restartFromZipUrl (viewer.ts:991-1003, worker.ts:115-118)"""
+        from .containers import fetch_bytes
+        self.restart_from_zip(fetch_bytes(url), n_threads)
+
+    def restart_from_urls(self, urls, n_threads: int = 0):
+        """restartFromURLs (viewer.ts:1005-1017, worker.ts:120-123): one DICOM slice per URL, in the order given"""
+        from .containers import fetch_bytes
+        self.restart_from_files([fetch_bytes(u) for u in urls], n_threads)
+
+    def load_env(self, data):
+        """loadEnv (viewer.ts:1019-1033, worker.ts:77-90, hdr.rs:23-36): an encoded environment map.  Radiance RGBE is
+        decoded; OpenEXR raises (decode it elsewhere and call setup_env with the floats)."""
+        from .containers import decode_environment
+        try:
+            floats, w, h = decode_environment(data)
+        except ValueError as e:
+            raise VolxelError(str(e)) from None
+        self.setup_env({"floats": floats, "width": w, "height": h})
+
+    def load_env_from_url(self, url: str):
+        """loadEnvFromUrl (viewer.ts:1035-1040)"""
+        from .containers import fetch_bytes
+        self.load_env(fetch_bytes(url))
+
+    # -- viewer.ts:443-449,543-551,789-795: the light follows the camera ("backlight") ---------
+    def maybe_sync_light(self):
+        """maybeSyncLight (viewer.ts:789-795): lightDir = -(view - pos); assigning it to the direction widget
+        (cubeDirection.ts:177-206) normalises it and hands the unit vector back through the 'direction' event
+        (viewer.ts:536-541), so the uniform of the next frame is the unit vector from the look-at point to the camera.
+        As in the reference, restoring a settings file does NOT re-aim the light (viewer.ts:696-713 never calls it):
+        the file's lightDir is used until the camera is rotated or the toggle changes."""
+        if self.settings.sync_light_dir:
+            d = np.asarray(self.camera.pos, dtype=np.float64) - np.asarray(self.camera.view, dtype=np.float64)
+            n = float(np.linalg.norm(d))
+            if n > 0.0:                                    # the widget ignores a zero vector (cubeDirection.ts:187-190)
+                self.settings.light_dir = (float(d[0] / n), float(d[1] / n), float(d[2] / n))
+
+    def rotate_camera(self, by):
+        """the canvas drag of viewer.ts:443-449: orbit, re-aim the synced light, restart"""
+        self.camera.rotate_around_view(by)
+        self.maybe_sync_light()
+        self.restart_rendering()
+
+    @property
+    def sync_light_dir(self) -> bool:
+        return bool(self.settings.sync_light_dir)
+
+    @sync_light_dir.setter
+    def sync_light_dir(self, on: bool):               # the backlight toggle, viewer.ts:543-551
+        self.settings.sync_light_dir = bool(on)
+        self.maybe_sync_light()
+        self.restart_rendering()
 
     # -- viewer.ts:1073-1078 setupEnv(WasmWorkerMessageEnvReturn) -----------------------------
     def setup_env(self, env_message):

@@ -83,17 +83,76 @@ def translate_m(v) -> np.ndarray:
     return m
 
 
+def _quat_axis(axis, rad):
+    """math.gl Quaternion.fromAxisRotation (gl-matrix quat.setAxisAngle): (x, y, z, w)"""
+    s = math.sin(rad * 0.5)
+    return np.array([axis[0] * s, axis[1] * s, axis[2] * s, math.cos(rad * 0.5)])
+
+
+def _quat_mul(a, b):
+    """gl-matrix quat.multiply(out, a, b) = a * b"""
+    ax, ay, az, aw = a
+    bx, by, bz, bw = b
+    return np.array([ax * bw + aw * bx + ay * bz - az * by, ay * bw + aw * by + az * bx - ax * bz,
+                     az * bw + aw * bz + ax * by - ay * bx, aw * bw - ax * bx - ay * by - az * bz])
+
+
+def _quat_rotate(v, q):
+    """gl-matrix vec3.transformQuat"""
+    qv, w = np.asarray(q[:3]), q[3]
+    uv = np.cross(qv, v)
+    uuv = np.cross(qv, uv)
+    return np.asarray(v, dtype=np.float64) + 2.0 * w * uv + 2.0 * uuv
+
+
 class Camera:
-    """scene.ts:3-72 (orbit controls omitted: input handling is out of scope)."""
+    """scene.ts:3-72: orbit camera.  The pointer handling that feeds the orbit methods is browser UI (out of scope);
+    the methods themselves are part of the component's behaviour (the light follows the camera through them,
+    viewer.ts:443-449,789-795)."""
 
     up = np.array([0.0, 1.0, 0.0])
 
     def __init__(self, distance: float = 1.0):
         self.view = np.zeros(3)                       # look-at point (scene.ts:11)
         self.pos = np.array([0.0, 0.0, -distance])    # scene.ts:12
+        self.yaw = 0.0                                # scene.ts:6-7
+        self.pitch = 0.0
         # [build] None: the reference's perspective camera; a number: orthographic camera whose image
         # spans +-ortho_half_height world units vertically (BASELINE config 1: 0.6)
         self.ortho_half_height: float | None = None
+
+    def rotate_around_view(self, by):                 # scene.ts:15-33
+        self.yaw += -float(by[0])
+        self.pitch += float(by[1])
+        max_pitch = math.pi / 2 - 0.01
+        self.pitch = min(max(self.pitch, -max_pitch), max_pitch)
+        q_yaw = _quat_axis(Camera.up, self.yaw)
+        right = _quat_rotate(np.array([1.0, 0.0, 0.0]), q_yaw)
+        right = right / np.linalg.norm(right)
+        q_pitch = _quat_axis(right, self.pitch)
+        orientation = _quat_mul(q_pitch, q_yaw)
+        dist = float(np.linalg.norm(np.asarray(self.pos, dtype=np.float64) - self.view))
+        self.pos = _quat_rotate(np.array([0.0, 0.0, -1.0]), orientation) * dist + self.view
+
+    def zoom(self, by: float) -> bool:                # scene.ts:35-40
+        d = np.asarray(self.pos, dtype=np.float64) - self.view
+        n = float(np.linalg.norm(d))
+        if n * by <= 0.1 or n * by >= 10:
+            return False
+        self.pos = d * by + self.view
+        return True
+
+    def translate_on_plane(self, by):                 # scene.ts:42-47
+        d = np.asarray(self.pos, dtype=np.float64) - self.view
+        right = np.cross(d, Camera.up)
+        right = right / np.linalg.norm(right)
+        local_up = np.cross(d, right)
+        local_up = local_up / np.linalg.norm(local_up)
+        self.translate(right * (float(by[0]) * 5) + local_up * (-float(by[1]) * 5))
+
+    def translate(self, by):                          # scene.ts:49-52
+        self.pos = np.asarray(self.pos, dtype=np.float64) + by
+        self.view = np.asarray(self.view, dtype=np.float64) + by
 
     def view_matrix(self) -> np.ndarray:
         return look_at(self.pos, self.view, Camera.up)
