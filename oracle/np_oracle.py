@@ -170,7 +170,10 @@ class NpVolume:
         return np.where(ok, fma(un, mx - mn, mn), F32(0))
 
     def trilinear(self, scale, px, py, pz):  # common.glsl:61-69
-        q = [np.asarray(a, dtype=F32) - F32(0.5) for a in (px, py, pz)]
+        return self.trilinear_q(scale, *[np.asarray(a, dtype=F32) - F32(0.5) for a in (px, py, pz)])
+
+    def trilinear_q(self, scale, qx, qy, qz):  # the same from the cell-frame position q = p - 1/2
+        q = [np.asarray(a, dtype=F32) for a in (qx, qy, qz)]
         fl = [np.floor(a) for a in q]
         f = [a - b for a, b in zip(q, fl)]
         i = [b.astype(np.int64) for b in fl]
@@ -241,17 +244,25 @@ def dvr_image(p, grid, tf, L, max_iter=100000):
     C = [np.zeros_like(tex_x) for _ in range(3)]
     T = np.ones_like(tex_x)
     tau = np.zeros_like(tex_x)
-    alive = hit.copy()
+    # [build] march contract: the ray has n = min(ceil((far - t0) / dt), max_steps) samples
+    # (0 unless the quotient is positive); sample k sits at q = fma(k, dq, q0) in the cell frame (position - 1/2),
+    # dq = dt * idir, q0 = fma(t0, idir, ipos) - 1/2, per axis
+    with np.errstate(divide="ignore", invalid="ignore"):
+        x = (far - t0) / dt
+    n = np.where(x > 0, np.minimum(np.ceil(x), F32(p.dvr_max_steps)), F32(0)).astype(F32)
+    n = np.where(hit, n, F32(0))
+    dq = [dt * idr[i] for i in range(3)]
+    q0 = [fma(t0, idr[i], ip[i]) - F32(0.5) for i in range(3)]
+    done_all = np.zeros_like(hit)
     samples = 0
     k = 0
-    while alive.any() and k < max_iter:
-        t = fma(F32(k), dt, t0)
-        alive &= t < far
+    while k < max_iter:
+        alive = (F32(k) < n) & ~done_all
         if not alive.any():
             break
         samples += int(alive.sum())
-        pos = [fma(t, idr[i], ip[i]) for i in range(3)]
-        dens = vol.trilinear(p.volume_density_scale, *pos)
+        q = [fma(F32(k), dq[i], q0[i]) for i in range(3)]
+        dens = vol.trilinear_q(p.volume_density_scale, *q)
         rgba = transfer(tf, L, p.sample_range, dens * F32(p.volume_inv_maj))
         a = np.where(alive, rgba[..., 3], F32(0))
         pos_a = a > 0
@@ -264,7 +275,7 @@ def dvr_image(p, grid, tf, L, max_iter=100000):
         tau = np.where(pos_a, tau_n, tau)
         done = pos_a & (tau >= F32(p.dvr_ert_tau))
         T = np.where(done, F32(0), T)
-        alive &= ~done
+        done_all |= done
         k += 1
     nl = [-F32(p.light_dir[i]) for i in range(3)]
     cdot = gmax(fma(d[2], nl[2], fma(d[1], nl[1], d[0] * nl[0])), zero)

@@ -1095,10 +1095,11 @@ void vxo_build_skip_mask(const VxParams* p, const VxoVolume* v, const float* tf,
       }
   free(bt);
 }
-static inline int sample_is_skipped(const Ctx* k, v3 ip) {
+/* is trilinear cell c (= floor of the cell-frame position) in a macro cell flagged empty? */
+static inline int cell_is_skipped(const Ctx* k, int32_t c0, int32_t c1, int32_t c2) {
   if (!k->skip_bits) return 0;
   int sh = 3 + k->skip_level;
-  int32_t cx = f2i(floorf(ip.x - 0.5f)) + 1, cy = f2i(floorf(ip.y - 0.5f)) + 1, cz = f2i(floorf(ip.z - 0.5f)) + 1;
+  int32_t cx = c0 + 1, cy = c1 + 1, cz = c2 + 1;
   if (cx < 0 || cy < 0 || cz < 0) return 0;
   uint32_t mx = (uint32_t)cx >> sh, my = (uint32_t)cy >> sh, mz = (uint32_t)cz >> sh;
   if (mx >= k->skip_dims[0] || my >= k->skip_dims[1] || mz >= k->skip_dims[2]) return 0;
@@ -1123,15 +1124,26 @@ static void dvr_pixel(Ctx* k, Ray ray, float start_offset, int phong, float out[
     float dt = p->dvr_step_voxels / sqrtf(dot3(idir, idir));
     float t0 = fmaf(start_offset, dt, near);
     float tau = 0.0f, kf = 0.0f;
+    /* [build] march contract: the ray has n = min(ceil((far - t0) / dt), max_steps) samples
+       (none unless the quotient is positive); sample k sits at q = fma(k, dq, q0) in the cell frame of A5
+       (position - 1/2), dq = dt * idir, q0 = fma(t0, idir, ipos) - 1/2, per axis.  (The first form walked
+       t_k = fma(k, dt, t0) and formed fma(t_k, idir, ipos) - 1/2: one more rounding and five more operations per
+       sample for the same line.) */
+    const float xq = (far - t0) / dt;
+    const float nf = (xq > 0.0f) ? fminf(ceilf(xq), (float)p->dvr_max_steps) : 0.0f;
+    const v3 dq = V3(dt * idir.x, dt * idir.y, dt * idir.z);
+    const v3 q0 = V3(fmaf(t0, idir.x, ipos.x) - 0.5f, fmaf(t0, idir.y, ipos.y) - 0.5f, fmaf(t0, idir.z, ipos.z) - 0.5f);
     v3 nl = V3(-p->light_dir[0], -p->light_dir[1], -p->light_dir[2]);
     v3 hv = V3(0, 0, 0);
     if (phong) hv = normalize3(sub3(nl, ray.d)); /* Blinn half vector of l and v = -dir */
-    for (int32_t i = 0; i < p->dvr_max_steps; ++i, kf += 1.0f) {
-      float t = fmaf(kf, dt, t0);
-      if (!(t < far)) break;
-      v3 ip = madd3(ipos, t, idir);
-      if (sample_is_skipped(k, ip)) { k->c.skip_steps++; continue; } /* alpha would be exactly 0 */
-      float d = trilinear(k, ip);
+    for (; kf < nf; kf += 1.0f) {
+      const float qx = fmaf(kf, dq.x, q0.x), qy = fmaf(kf, dq.y, q0.y), qz = fmaf(kf, dq.z, q0.z);
+      const float flx = floorf(qx), fly = floorf(qy), flz = floorf(qz);
+      const float fx = qx - flx, fy = qy - fly, fz = qz - flz;
+      const int32_t cx = f2i(flx), cy = f2i(fly), cz = f2i(flz);
+      if (cell_is_skipped(k, cx, cy, cz)) { k->c.skip_steps++; continue; } /* alpha would be exactly 0 */
+      /* lookup_density_trilinear, common.glsl:61-69, from the cell and fractions of q */
+      float d = vxo_trilinear_cell(k->v, p->volume_density_scale, cx, cy, cz, fx, fy, fz);
       float rgba[4];
       lookup_transfer(k, d * p->volume_inv_maj, rgba);
       k->c.samples++;
@@ -1143,10 +1155,6 @@ static void dvr_pixel(Ctx* k, Ray ray, float start_offset, int phong, float out[
              read the cells c +- e with the sample's fractions -- fract((p +- 1) - 0.5) equals fract(p - 0.5)
              mathematically, and forming it from the rounded p +- 1 would only add rounding noise.  World
              gradient = g_i * Minv_ii */
-          float qx = ip.x - 0.5f, qy = ip.y - 0.5f, qz = ip.z - 0.5f;
-          float flx = floorf(qx), fly = floorf(qy), flz = floorf(qz);
-          float fx = qx - flx, fy = qy - fly, fz = qz - flz;
-          int32_t cx = f2i(flx), cy = f2i(fly), cz = f2i(flz);
           const float ds = p->volume_density_scale;
           float gx = vxo_trilinear_cell(k->v, ds, cx + 1, cy, cz, fx, fy, fz) - vxo_trilinear_cell(k->v, ds, cx - 1, cy, cz, fx, fy, fz);
           float gy = vxo_trilinear_cell(k->v, ds, cx, cy + 1, cz, fx, fy, fz) - vxo_trilinear_cell(k->v, ds, cx, cy - 1, cz, fx, fy, fz);

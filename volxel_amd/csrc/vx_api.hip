@@ -598,7 +598,10 @@ static int alloc_layout(VxContext* c, uint32_t& n_layers) {
     if (n_vox / 4u > 0xffffffffull)
       VX_FAIL(c, VX_ERR_INVALID, "volume too large for the brickf32 layout (%llu voxels): select VX_LAYOUT_REFERENCE "
               "with vx_set_layout", (unsigned long long)n_vox);
-    VX_HIP(c, hipMalloc(&c->bf_alloc, n_vox * sizeof(float)));
+    // + one zero 16-byte chunk behind the last brick: the window staging of the LDS kernel reads it for rows and
+    // chunks outside the volume (one select per load instead of a branch and a zero fill)
+    VX_HIP(c, hipMalloc(&c->bf_alloc, n_vox * sizeof(float) + 16));
+    VX_HIP(c, hipMemsetAsync((char*)c->bf_alloc + n_vox * sizeof(float), 0, 16, c->stream));
     c->dv.bf = (const float*)c->bf_alloc;
     n_layers = c->dv.bc[2];
     return VX_OK;
@@ -649,7 +652,8 @@ static int ensure_brickf32(VxContext* c) {
   if (c->dv.bf) return VX_OK;
   const uint64_t n_vox = (uint64_t)c->dv.bc[0] * c->dv.bc[1] * c->dv.bc[2] * 512u;
   if (n_vox / 4u > 0xffffffffull) return VX_OK;   // too large: the generic kernel serves Phong
-  VX_HIP(c, hipMalloc(&c->bf_alloc, n_vox * sizeof(float)));
+  VX_HIP(c, hipMalloc(&c->bf_alloc, n_vox * sizeof(float) + 16));   // + the zero chunk (alloc_layout)
+  VX_HIP(c, hipMemsetAsync((char*)c->bf_alloc + n_vox * sizeof(float), 0, 16, c->stream));
   c->dv.bf = (const float*)c->bf_alloc;
   for (uint64_t at = 0; at < n_vox;) {
     uint64_t n = n_vox - at < (1ull << 31) ? n_vox - at : (1ull << 31);

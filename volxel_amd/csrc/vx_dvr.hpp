@@ -13,9 +13,12 @@
 
 namespace vx {
 
+// [build] march contract (oracle/vx_oracle.c dvr_pixel): a ray has n samples, sample k sits at
+// q = fma(k, dq, q0) in the cell frame of A5 (position - 1/2)
 struct DvrRay {
-  V3 ipos, idir;   // index-space origin / direction (raymarch.glsl:31-32)
-  float t0, dt, far;
+  V3 q0, dq;       // cell-frame position of sample 0, increment per sample (index space, raymarch.glsl:31-32)
+  float dt;        // world-space step (optical depth per sample = alpha * maj * dt)
+  float n;         // number of samples: min(ceil((far - t0) / dt), max_steps); 0 for a miss
   V3 wdir;         // world-space direction (for the environment term)
   bool hit;
 };
@@ -34,11 +37,16 @@ VXD DvrRay dvr_setup(const VxParams& p, int px, int py, uint32_t frame) {
   }
   Ray ray = setup_world_ray(p, tex_x, tex_y, jx, jy);
   DvrRay r;
-  float near;
-  r.hit = ray_box_intersection(ray, p.volume_aabb_min, p.volume_aabb_max, near, r.far);
-  to_index(p, ray, r.ipos, r.idir);
-  r.dt = p.dvr_step_voxels / sqrtf(dot3(r.idir, r.idir));
-  r.t0 = fma_(off, r.dt, near);
+  float near, far;
+  V3 ipos, idir;
+  r.hit = ray_box_intersection(ray, p.volume_aabb_min, p.volume_aabb_max, near, far);
+  to_index(p, ray, ipos, idir);
+  r.dt = p.dvr_step_voxels / sqrtf(dot3(idir, idir));
+  const float t0 = fma_(off, r.dt, near);
+  const float x = (far - t0) / r.dt;
+  r.n = (r.hit && x > 0.0f) ? fminf(ceilf(x), (float)p.dvr_max_steps) : 0.0f;
+  r.dq = v3(r.dt * idir.x, r.dt * idir.y, r.dt * idir.z);
+  r.q0 = v3(fma_(t0, idir.x, ipos.x) - 0.5f, fma_(t0, idir.y, ipos.y) - 0.5f, fma_(t0, idir.z, ipos.z) - 0.5f);
   r.wdir = ray.d;
   return r;
 }
@@ -118,9 +126,7 @@ __global__ __launch_bounds__(256) void render_dvr_cq(const VxParams p, const Dev
   const float4* __restrict__ cq = v.cq;
   const uint32_t cmaxx = v.extent[0] + 7u, cmaxy = v.extent[1] + 7u, cmaxz = v.extent[2] + 7u;
   const float ert = p.dvr_ert_tau;
-  const float max_steps_f = (float)p.dvr_max_steps;
   const uint32_t sh = 3u + v.skip_level, md0 = v.skip_dims[0], md1 = v.skip_dims[1];
-  const float inv_dt = SKIP ? 1.0f / r.dt : 0.0f;
 
   float Cx = 0.f, Cy = 0.f, Cz = 0.f, T = 1.0f, tau = 0.0f, kf = 0.0f;  // kf: per-lane step index
   uint32_t n_samples = 0, n_slots = 0, n_skipped = 0, n_batches = 0;    // wave-uniform
@@ -128,8 +134,7 @@ __global__ __launch_bounds__(256) void render_dvr_cq(const VxParams p, const Dev
 
   while (true) {
     {
-      float t = fma_(kf, r.dt, r.t0);
-      alive = alive && (t < r.far) && (kf < max_steps_f);
+      alive = alive && (kf < r.n);
       if (__ballot(alive) == 0ull) break;
     }
     n_batches += 1u;
@@ -142,12 +147,12 @@ __global__ __launch_bounds__(256) void render_dvr_cq(const VxParams p, const Dev
     uint32_t lcx = 0, lcy = 0, lcz = 0;
 #pragma unroll
     for (int u = 0; u < U; ++u) {
-      float t = fma_(kf + (float)u, r.dt, r.t0);
-      bool in = alive && (t < r.far) && (kf + (float)u < max_steps_f);
+      const float ku = kf + (float)u;
+      bool in = alive && (ku < r.n);
       // A5 on the cellquad layout: cell (floor(p-0.5)) + 1 -> apron brick / local cell
-      float qx = fma_(t, r.idir.x, r.ipos.x) - 0.5f;
-      float qy = fma_(t, r.idir.y, r.ipos.y) - 0.5f;
-      float qz = fma_(t, r.idir.z, r.ipos.z) - 0.5f;
+      float qx = fma_(ku, r.dq.x, r.q0.x);
+      float qy = fma_(ku, r.dq.y, r.q0.y);
+      float qz = fma_(ku, r.dq.z, r.q0.z);
       float flx = floorf(qx), fly = floorf(qy), flz = floorf(qz);
       fx[u] = qx - flx; fy[u] = qy - fly; fz[u] = qz - flz;
       uint32_t cx = (uint32_t)((int)flx + 1), cy = (uint32_t)((int)fly + 1), cz = (uint32_t)((int)flz + 1);
@@ -232,15 +237,14 @@ __global__ __launch_bounds__(256) void render_dvr_cq(const VxParams p, const Dev
     }
     kf += (float)U;
     if (SKIP && last_empty) {
-      // distance (in t) from the batch's last sample to the faces of its macro cell, along the ray
+      // steps from the batch's last sample to the faces of its macro cell, along the ray (dq = index units per step)
       const float Sf = (float)(1u << sh);
       float bx = (float)((lcx >> sh) << sh) - 1.0f, by = (float)((lcy >> sh) << sh) - 1.0f,
             bz = (float)((lcz >> sh) << sh) - 1.0f;  // q in [b, b + S) inside the macro cell
-      float dx = r.idir.x > 0.0f ? (bx + Sf - lqx) / r.idir.x : (r.idir.x < 0.0f ? (bx - lqx) / r.idir.x : 3.0e38f);
-      float dy = r.idir.y > 0.0f ? (by + Sf - lqy) / r.idir.y : (r.idir.y < 0.0f ? (by - lqy) / r.idir.y : 3.0e38f);
-      float dz = r.idir.z > 0.0f ? (bz + Sf - lqz) / r.idir.z : (r.idir.z < 0.0f ? (bz - lqz) / r.idir.z : 3.0e38f);
-      float dmin = fminf(dx, fminf(dy, dz));
-      float n = floorf(dmin * inv_dt) - 2.0f;  // stay >= one whole step short of the exit face
+      float dx = r.dq.x > 0.0f ? (bx + Sf - lqx) / r.dq.x : (r.dq.x < 0.0f ? (bx - lqx) / r.dq.x : 3.0e38f);
+      float dy = r.dq.y > 0.0f ? (by + Sf - lqy) / r.dq.y : (r.dq.y < 0.0f ? (by - lqy) / r.dq.y : 3.0e38f);
+      float dz = r.dq.z > 0.0f ? (bz + Sf - lqz) / r.dq.z : (r.dq.z < 0.0f ? (bz - lqz) / r.dq.z : 3.0e38f);
+      float n = floorf(fminf(dx, fminf(dy, dz))) - 2.0f;  // stay >= one whole step short of the exit face
       n = fminf(n, 1048576.0f);
       if (n >= 1.0f) kf += n;
     }
@@ -339,9 +343,7 @@ __global__ __launch_bounds__(256) void render_dvr_dp(const VxParams p, const Dev
   const float4* __restrict__ cq = v.cq;
   const uint32_t cmaxx = v.extent[0] + 7u, cmaxy = v.extent[1] + 7u, cmaxz = v.extent[2] + 7u;
   const float ert = p.dvr_ert_tau;
-  const float max_steps_f = (float)p.dvr_max_steps;
   const uint32_t sh = 3u + v.skip_level, md0 = v.skip_dims[0], md1 = v.skip_dims[1];
-  const float inv_dt = SKIP ? 1.0f / r.dt : 0.0f;
   const float jf = (float)j;
 
   float Cx = 0.f, Cy = 0.f, Cz = 0.f;   // per-lane partial colour sums
@@ -351,17 +353,15 @@ __global__ __launch_bounds__(256) void render_dvr_dp(const VxParams p, const Dev
 
   while (true) {
     {
-      float t = fma_(kb, r.dt, r.t0);    // first step of the group decides whether the ray goes on
-      ray_alive = ray_alive && (t < r.far) && (kb < max_steps_f);
+      ray_alive = ray_alive && (kb < r.n);   // first step of the group decides whether the ray goes on
       if (__ballot(ray_alive) == 0ull) break;
     }
     const float k = kb + jf;
-    const float t = fma_(k, r.dt, r.t0);
-    const bool in = ray_alive && (t < r.far) && (k < max_steps_f);
+    const bool in = ray_alive && (k < r.n);
     // A5 on the cellquad layout (as render_dvr_cq)
-    float qx = fma_(t, r.idir.x, r.ipos.x) - 0.5f;
-    float qy = fma_(t, r.idir.y, r.ipos.y) - 0.5f;
-    float qz = fma_(t, r.idir.z, r.ipos.z) - 0.5f;
+    float qx = fma_(k, r.dq.x, r.q0.x);
+    float qy = fma_(k, r.dq.y, r.q0.y);
+    float qz = fma_(k, r.dq.z, r.q0.z);
     float flx = floorf(qx), fly = floorf(qy), flz = floorf(qz);
     float fx = qx - flx, fy = qy - fly, fz = qz - flz;
     uint32_t cx = (uint32_t)((int)flx + 1), cy = (uint32_t)((int)fly + 1), cz = (uint32_t)((int)flz + 1);
@@ -433,10 +433,10 @@ __global__ __launch_bounds__(256) void render_dvr_dp(const VxParams p, const Dev
         const float Sf = (float)(1u << sh);
         float bx = (float)((cx >> sh) << sh) - 1.0f, by = (float)((cy >> sh) << sh) - 1.0f,
               bz = (float)((cz >> sh) << sh) - 1.0f;
-        float dx = r.idir.x > 0.0f ? (bx + Sf - qx) / r.idir.x : (r.idir.x < 0.0f ? (bx - qx) / r.idir.x : 3.0e38f);
-        float dy = r.idir.y > 0.0f ? (by + Sf - qy) / r.idir.y : (r.idir.y < 0.0f ? (by - qy) / r.idir.y : 3.0e38f);
-        float dz = r.idir.z > 0.0f ? (bz + Sf - qz) / r.idir.z : (r.idir.z < 0.0f ? (bz - qz) / r.idir.z : 3.0e38f);
-        float n = floorf(fminf(dx, fminf(dy, dz)) * inv_dt) - 2.0f;
+        float dx = r.dq.x > 0.0f ? (bx + Sf - qx) / r.dq.x : (r.dq.x < 0.0f ? (bx - qx) / r.dq.x : 3.0e38f);
+        float dy = r.dq.y > 0.0f ? (by + Sf - qy) / r.dq.y : (r.dq.y < 0.0f ? (by - qy) / r.dq.y : 3.0e38f);
+        float dz = r.dq.z > 0.0f ? (bz + Sf - qz) / r.dq.z : (r.dq.z < 0.0f ? (bz - qz) / r.dq.z : 3.0e38f);
+        float n = floorf(fminf(dx, fminf(dy, dz))) - 2.0f;
         n = (ray_alive && last_slot) ? fminf(n, 1048576.0f) : 1048576.0f;
         int ni = wave_min_i32((int)fmaxf(n, 0.0f));
         if (ni >= 1) kb += (float)ni;

@@ -106,6 +106,8 @@ VXD float mix8(float v000, float v100, float v010, float v110, float v001, float
 #ifndef VX_W_LDS_PHONG
 #define VX_W_LDS_PHONG 7
 #endif
+typedef const float __attribute__((address_space(3))) * LdsFloatPtr;
+
 template <int S, bool PHONG, bool SKIP>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(PHONG ? (SKIP ? 1 : VX_W_LDS_PHONG) : (SKIP ? VX_W_LDS_SKIP : VX_W_LDS), 8))) void render_dvr_lds(const VxParams p, const DevVolume v,
                                                        const float4* __restrict__ tf_global, uint32_t tf_len,
@@ -138,9 +140,9 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(PHONG ? (SK
   if (in_image) r = dvr_setup(p, px, py, frame);
   const bool hit0 = in_image && r.hit;
   const uint32_t n_rays = (uint32_t)__builtin_popcountll(ballot(hit0));
-  // a lane is live while its next sample lies before `far`; a lane that misses, leaves the image or terminates
-  // gets far = -inf, so liveness is recomputed from registers each step instead of being carried as a flag
-  float far = hit0 ? r.far : -__builtin_inff();
+  // samples the lane's ray still has: k = 0 .. nray - 1 (march contract, vx_dvr.hpp); a ray that terminates early
+  // gets nray = -1, so liveness is `kf < nray` -- one compare on registers the loop holds anyway
+  float nray = hit0 ? r.n : 0.0f;
 
   float scale = p.volume_density_scale;
   asm volatile("" : "+v"(scale));   // keep it in a VGPR: out of SGPRs the allocator re-loaded it from the kernel
@@ -150,37 +152,36 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(PHONG ? (SK
   const float lenf = (float)tf_len;
   const int last = (int)tf_len - 1;
   const float ert = p.dvr_ert_tau;
-  const float max_steps_f = (float)p.dvr_max_steps;
   const uint32_t ex = v.extent[0], ey = v.extent[1], ez = v.extent[2];
   const uint32_t bcx = v.bc[0], bcy = v.bc[1];
   const float4* __restrict__ bf4 = reinterpret_cast<const float4*>(v.bf);   // 16-byte units: 64 GiB of layout in 32 bits
+  const uint32_t zero_chunk = bcx * bcy * v.bc[2] * 128u;   // the all-zero chunk behind the last brick (vx_api alloc_layout)
   const uint32_t sh = 3u + v.skip_level, md0 = v.skip_dims[0], md1 = v.skip_dims[1];
   const uint32_t cmaxx = ex + 7u, cmaxy = ey + 7u, cmaxz = ez + 7u;
-  // jumps over empty macro cells are sized in steps: only with steps well above the rounding of a sample position
-  // (2^-14 voxel at coordinate 1024); finer marches skip sample by sample
-  const float inv_dt = (SKIP && p.dvr_step_voxels >= 0.015625f) ? 1.0f / r.dt : 0.0f;
   // Phong terms (vx_modes.hpp Frame::dvr<true>)
   V3 nl = v3(-p.light_dir[0], -p.light_dir[1], -p.light_dir[2]);
   V3 hv = v3(0.f, 0.f, 0.f);
   if (PHONG) hv = normalize3(sub3(nl, r.wdir));
   const float gsx = p.density_transform_inv[0], gsy = p.density_transform_inv[5], gsz = p.density_transform_inv[10];
+  // steps per index unit along each axis, for the number of steps a lane can take inside a window; an axis the ray
+  // does not move along gets a huge factor: any distance to a face times it exceeds every step count
+  // (v_rcp_f32: the quotient only feeds estimates that an exact test confirms or that are conservative by a step)
+  const float ivx = r.dq.x != 0.0f ? __builtin_amdgcn_rcpf(r.dq.x) : 3.0e38f;
+  const float ivy = r.dq.y != 0.0f ? __builtin_amdgcn_rcpf(r.dq.y) : 3.0e38f;
+  const float ivz = r.dq.z != 0.0f ? __builtin_amdgcn_rcpf(r.dq.z) : 3.0e38f;
 
   float Cx = 0.f, Cy = 0.f, Cz = 0.f, T = 1.0f, tau = 0.0f, kf = 0.0f;   // kf: per-lane step index
   uint32_t n_samples = 0, n_slots = 0, n_skipped = 0, n_grads = 0, n_loads = 0, n_reads = 0;   // wave-uniform
 
-  // cell of the lane's next sample
-  float t = 0.f, qx = 0.f, qy = 0.f, qz = 0.f, flx = 0.f, fly = 0.f, flz = 0.f;
-  int cxi = 0, cyi = 0, czi = 0;
-  // liveness is a function of registers (t, far, kf), evaluated where it is needed: a flag carried around the march
-  // loop costs a VGPR and four instructions per step to convert between flag and lane mask
-  auto is_alive = [&]() { return (t < far) & (kf < max_steps_f); };
+  // cell-frame position of the lane's next sample and its floor (the cell), as floats: the march needs no integer
+  // cell -- the tile offset is formed in floating point (exact: small integers) and converted once
+  float qx = 0.f, qy = 0.f, qz = 0.f, flx = 0.f, fly = 0.f, flz = 0.f;
+  auto is_alive = [&]() { return kf < nray; };
   auto next_sample = [&]() {
-    t = fma_(kf, r.dt, r.t0);
-    qx = fma_(t, r.idir.x, r.ipos.x) - 0.5f;
-    qy = fma_(t, r.idir.y, r.ipos.y) - 0.5f;
-    qz = fma_(t, r.idir.z, r.ipos.z) - 0.5f;
+    qx = fma_(kf, r.dq.x, r.q0.x);
+    qy = fma_(kf, r.dq.y, r.q0.y);
+    qz = fma_(kf, r.dq.z, r.q0.z);
     flx = floorf(qx); fly = floorf(qy); flz = floorf(qz);
-    cxi = (int)flx; cyi = (int)fly; czi = (int)flz;
   };
   next_sample();
 
@@ -191,9 +192,9 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(PHONG ? (SK
     const unsigned long long live0 = ballot(is_alive());
     if (live0 != 0ull) {
       const int first = (int)__builtin_ctzll(live0);
-      fwx = __builtin_amdgcn_readlane(__builtin_bit_cast(int, r.idir.x), first) >= 0;   // sign bit clear
-      fwy = __builtin_amdgcn_readlane(__builtin_bit_cast(int, r.idir.y), first) >= 0;
-      fwz = __builtin_amdgcn_readlane(__builtin_bit_cast(int, r.idir.z), first) >= 0;
+      fwx = __builtin_amdgcn_readlane(__builtin_bit_cast(int, r.dq.x), first) >= 0;   // sign bit clear
+      fwy = __builtin_amdgcn_readlane(__builtin_bit_cast(int, r.dq.y), first) >= 0;
+      fwz = __builtin_amdgcn_readlane(__builtin_bit_cast(int, r.dq.z), first) >= 0;
     }
   }
   int LOx = 0, LOy = 0, LOz = 0;   // origin of the resident window (wave uniform)
@@ -217,18 +218,56 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(PHONG ? (SK
     return (rx < (uint32_t)(DX - TL::LO_MARGIN - TL::HI_MARGIN)) & (ry < (uint32_t)(DY - TL::LO_MARGIN - TL::HI_MARGIN)) &
            (rz < (uint32_t)(DZ - TL::LO_MARGIN - TL::HI_MARGIN));
   };
+  // ---- per window and lane: klim = the step index up to which the lane stays inside the resident window, so that the
+  // march tests ONE compare (kf < klim) per step instead of three cell ranges and two liveness compares.
+  // Along an axis the positions q(k) = fma(k, dq, q0) are monotone in k, so the steps a lane can take are the k below
+  // the first one at or beyond the face it moves towards.  c = ceil((face - q0) / dq) estimates that index; the exact
+  // test of q(c - 1) -- the very fma the march evaluates -- confirms that every sample below c is inside.  If the
+  // estimate was a step too high the lane falls back to the single step its current sample (tested on integer cells)
+  // allows; a step too low only ends the lane's run in this window one sample early.  Either way the lane never reads
+  // outside the tile and the window sequence only affects speed, never which samples are evaluated.
+  float klim = 0.0f;
+  int tile_base = 0;   // LDS byte address of cell (0,0,0) of the index grid in the resident tile (wave uniform)
+  const int tile_addr = (int)(uint32_t)(uintptr_t)(LdsFloatPtr)tile;   // LDS byte address of the wave's tile
+  auto axis_limit = [&](float q0a, float dqa, float iva, int lo_cell, int n_cells) {
+    // cells [lo_cell, lo_cell + n_cells) are steppable: lo <= q < hi
+    const float lo = (float)lo_cell, hi = lo + (float)n_cells;
+    const bool bw = dqa < 0.0f;
+    const float face = bw ? lo : hi;
+    float c = ceilf((face - q0a) * iva);
+    c = fminf(c, 16777216.0f);                       // also turns a NaN estimate into "far away"
+    const float q1 = fma_(c - 1.0f, dqa, q0a);
+    const bool in1 = (q1 < face) != bw;              // forward: q1 < hi; backward: q1 >= lo
+    return in1 ? c : -1.0f;
+  };
+  // `now`: the lane is alive and its current sample's cell is inside the window (exact_window has just tested it)
+  auto set_limits = [&](bool now) {
+    const float kx = axis_limit(r.q0.x, r.dq.x, ivx, LOx + TL::LO_MARGIN, DX - TL::LO_MARGIN - TL::HI_MARGIN);
+    const float ky = axis_limit(r.q0.y, r.dq.y, ivy, LOy + TL::LO_MARGIN, DY - TL::LO_MARGIN - TL::HI_MARGIN);
+    const float kz = axis_limit(r.q0.z, r.dq.z, ivz, LOz + TL::LO_MARGIN, DZ - TL::LO_MARGIN - TL::HI_MARGIN);
+    float k = fminf(kx, fminf(ky, kz));
+    k = fmaxf(k, kf + 1.0f);                         // the current sample is inside (integer test): one step at least
+    k = fminf(k, nray);
+    klim = now ? k : 0.0f;
+    tile_base = tile_addr - 4 * ((LOz * SS) + (LOy * RS) + LOx);
+  };
   // exact window for the lanes as they stand; lanes too far apart for one window (a wave astride two entry faces of
   // the clip box): serve the first live lane
+  // returns, per lane: alive and the current sample's cell inside the window placed
   auto exact_window = [&](unsigned long long live) {
     const bool alive = is_alive();
+    const int cxi = (int)flx, cyi = (int)fly, czi = (int)flz;
     anchor(alive, cxi, cyi, czi, 0, LOx, LOy, LOz);
-    if (ballot(alive & inside_of(LOx, LOy, LOz, cxi, cyi, czi)) == 0ull) {
+    bool now = alive & inside_of(LOx, LOy, LOz, cxi, cyi, czi);
+    if (ballot(now) == 0ull) {
       const int first = (int)__builtin_ctzll(live);
       LOx = __builtin_amdgcn_readlane(cxi, first) - TL::LO_MARGIN - (fwx ? 0 : DX - 1 - TL::LO_MARGIN - TL::HI_MARGIN);
       LOx = fwx ? (LOx & ~3) : ((LOx + 3) & ~3);
       LOy = __builtin_amdgcn_readlane(cyi, first) - TL::LO_MARGIN - (fwy ? 0 : DY - 1 - TL::LO_MARGIN - TL::HI_MARGIN);
       LOz = __builtin_amdgcn_readlane(czi, first) - TL::LO_MARGIN - (fwz ? 0 : DZ - 1 - TL::LO_MARGIN - TL::HI_MARGIN);
+      now = alive & inside_of(LOx, LOy, LOz, cxi, cyi, czi);
     }
+    return now;
   };
   // stage, part 1: lane = (y,z) row of the window at (ox,oy,oz): X / 4 aligned 16-byte loads into registers, issued
   // back to back; rows and chunks outside the volume are zeros (A4)
@@ -253,8 +292,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(PHONG ? (SK
                                ((((uint32_t)gz & 7u) << 4) | (((uint32_t)gy & 7u) << 1));
 #pragma unroll
       for (int c = 0; c < NC; ++c) {
-        float4 val = make_float4(0.f, 0.f, 0.f, 0.f);
-        if (rin && xin[c]) val = bf4[rowbase + xoff[c]];
+        const uint32_t at = (rin && xin[c]) ? rowbase + xoff[c] : zero_chunk;
+        const float4 val = bf4[at];
         vals[ps][c] = val;
       }
     }
@@ -283,34 +322,33 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(PHONG ? (SK
   // has alpha == 0 exactly) -------------------------------------------------------------------------------------------
   // is the lane's next sample in an empty macro cell?  (defined for every lane: the clamps keep the index in the mask)
   auto in_empty_cell = [&]() {
-    uint32_t cx = (uint32_t)(cxi + 1), cy = (uint32_t)(cyi + 1), cz = (uint32_t)(czi + 1);
+    uint32_t cx = (uint32_t)((int)flx + 1), cy = (uint32_t)((int)fly + 1), cz = (uint32_t)((int)flz + 1);
     cx = cx < cmaxx ? cx : cmaxx; cy = cy < cmaxy ? cy : cmaxy; cz = cz < cmaxz ? cz : cmaxz;
     const uint32_t mi = mad24(mad24(cz >> sh, md1, cy >> sh), md0, cx >> sh);   // at most 65536 macro cells
     return (bool)((mask_lds[mi >> 5] >> (mi & 31u)) & 1u);
   };
   // further steps a lane in an empty macro cell may pass over: it moves on to about one step short of the exit face of
   // the cell (vx_dvr.hpp does the same with the last sample of a batch); every sample passed over lies inside the same
-  // empty macro cell, so the set of evaluated samples is unchanged
-  // (reciprocals of the direction once per ray; a jump only has to be conservative: the error of the three products
-  // is below a quarter step for the longest jump taken, one whole step is kept in hand.  A zero component gets a
-  // huge negative factor: its distance to the lower face (<= 0) becomes huge and drops out of the minimum.)
-  const float jix = !SKIP ? 0.f : (r.idir.x != 0.0f ? 1.0f / r.idir.x : -3.0e38f);
-  const float jiy = !SKIP ? 0.f : (r.idir.y != 0.0f ? 1.0f / r.idir.y : -3.0e38f);
-  const float jiz = !SKIP ? 0.f : (r.idir.z != 0.0f ? 1.0f / r.idir.z : -3.0e38f);
+  // empty macro cell, so the set of evaluated samples is unchanged.  (iv* = steps per index unit; a jump only has to
+  // be conservative: one whole step is kept in hand against the rounding of the three products.  An axis the ray does
+  // not move along has a huge factor: its distance to the far face becomes huge and drops out of the minimum.)
+  // Only with steps well above the rounding of a sample position (2^-14 voxel at coordinate 1024); finer marches
+  // skip sample by sample.
+  const bool jumps = SKIP && p.dvr_step_voxels >= 0.015625f;
   auto jump_of = [&](bool emp) {
     const float Sf1 = (float)(1u << sh) - 1.0f;
-    uint32_t cx = (uint32_t)(cxi + 1), cy = (uint32_t)(cyi + 1), cz = (uint32_t)(czi + 1);
+    uint32_t cx = (uint32_t)((int)flx + 1), cy = (uint32_t)((int)fly + 1), cz = (uint32_t)((int)flz + 1);
     cx = cx < cmaxx ? cx : cmaxx; cy = cy < cmaxy ? cy : cmaxy; cz = cz < cmaxz ? cz : cmaxz;
     // q in [b - 1, b - 1 + S) inside the macro cell at b = (c >> sh) << sh; exit face along the ray
-    const float ex = (float)((cx >> sh) << sh) + (r.idir.x > 0.0f ? Sf1 : -1.0f);
-    const float ey = (float)((cy >> sh) << sh) + (r.idir.y > 0.0f ? Sf1 : -1.0f);
-    const float ez = (float)((cz >> sh) << sh) + (r.idir.z > 0.0f ? Sf1 : -1.0f);
-    const float dmin = fminf((ex - qx) * jix, fminf((ey - qy) * jiy, (ez - qz) * jiz));
+    const float fx_ = (float)((cx >> sh) << sh) + (r.dq.x < 0.0f ? -1.0f : Sf1);
+    const float fy_ = (float)((cy >> sh) << sh) + (r.dq.y < 0.0f ? -1.0f : Sf1);
+    const float fz_ = (float)((cz >> sh) << sh) + (r.dq.z < 0.0f ? -1.0f : Sf1);
+    const float dmin = fminf((fx_ - qx) * ivx, fminf((fy_ - qy) * ivy, (fz_ - qz) * ivz));
     // samples k+1 .. k+n are passed over unseen: n < (steps to the exit face) keeps them inside the cell -- one whole
-    // step in hand against the rounding of dmin (< 1/4 step, above); the sample the lane lands on is tested like any
-    float n = floorf(dmin * inv_dt) - 1.0f;
+    // step in hand against the rounding of dmin; the sample the lane lands on is tested like any
+    float n = floorf(dmin) - 1.0f;
     n = fminf(n, 1048576.0f);
-    return (emp && n >= 1.0f) ? n : 0.0f;
+    return (jumps && emp && n >= 1.0f) ? n : 0.0f;
   };
   // free flight: a sample in an empty macro cell needs no taps, hence no window -- before a window is placed the lanes
   // that stand in empty cells pass over them (jump, then step by step to the exit face) while the others wait, so
@@ -348,34 +386,39 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(PHONG ? (SK
       live = ballot(is_alive());
       if (live == 0ull) return false;
     }
-    exact_window(live);
+    const bool now = exact_window(live);
     if (SKIP) wtest = touches_empty();
+    set_limits(now);
     float4 vals[TL::PASSES][NC];
     issue_loads(LOx, LOy, LOz, vals);
     write_tile(vals);
     return true;
   };
 
-  // (Tried: issuing the loads of the NEXT window -- predicted from where every lane leaves the resident one -- before
-  // the march, into registers, so that their latency hides behind it.  With an exact-enough guess the windows and
-  // lane slots stayed the same, yet the frame took 0.452 instead of 0.437 ms: the 5-6 resident waves per SIMD already
-  // cover the staging latency, the guess and its wasted loads only added instructions.  Not kept.)
   {
     const unsigned long long live = ballot(is_alive());
     if (live != 0ull) {
       (void)next_window(live);
     }
   }
-  auto inside = [&](int cx, int cy, int cz) { return inside_of(LOx, LOy, LOz, cx, cy, cz); };
   // ---- 3. march: up to S steps out of LDS.  TEST (SKIP builds): the window touches an empty macro cell, the mask is
-  // tested per step; in the other windows the test is compiled out
+  // tested per step; in the other windows the test is compiled out.
+  // Per step and stepping lane (52 -> 36 vector instructions against the first form of this loop): one compare; the
+  // tile offset as two fmas on the float cells, one conversion, one shift-add; eight taps (four ds_read2_b32 at
+  // immediate offsets of one address); the 14-instruction mix; scale; range test; then index + 1, the next position
+  // (three fmas) and its floors.  (The body under `if (go)` -- EXEC = the stepping lanes -- was tried: the compiler
+  // answered the divergent region with 22 register copies per step for the values it carries round the loop.)
   auto march = [&](auto test_tag) {
     constexpr bool TEST = decltype(test_tag)::value;
+    // One exit, tested at the bottom on the updated registers (a window is only placed where a lane can step, so the
+    // first trip always has one): with the test at the top the loop had two exits that leave different versions of
+    // every carried value live, and the compiler paid for the merge with 20 register copies per step.
+    int s = 0;
+    bool more;
+    bool go = kf < klim;     // carried: the bottom test of one trip is the lane mask of the next
 #pragma unroll 1
-    for (int s = 0; s < S; ++s) {
-      const bool go = is_alive() & inside(cxi, cyi, czi);
-      const unsigned long long gm = ballot(go);
-      if (gm == 0ull) break;                      // nobody can step in this window any more: restage
+    do {
+      n_slots += 64u;
       bool eval = go;
       float jump = 0.0f;   // SKIP: further steps this lane may pass over (all inside the same empty macro cell)
       if (TEST) {
@@ -386,16 +429,15 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(PHONG ? (SK
         n_skipped += (uint32_t)__builtin_popcountll(em);
         if (em != 0ull) jump = jump_of(emp);      // wave uniform
       }
-      n_slots += 64u;
-      // (without skipping a lane evaluates one sample per step it takes: its count is kf after the march; counting
-      // per step costs a select and a compare to turn the conjunction `go` into a lane mask)
+      // (without skipping a lane evaluates one sample per step it takes: its count is kf after the march)
       if (SKIP) n_samples += (uint32_t)__builtin_popcountll(ballot(eval));
-      // word offset of the sample's cell in the tile.  Stepping lanes: all three differences are in [0, 16): 24-bit
-      // multiplies (full rate) instead of v_mul_lo_u32.  The other lanes read wherever their stale cell points: an LDS
-      // read cannot fault (out of range it returns 0), and whatever they read ends in alpha = 0 (in_range has `go`).
-      const int off = (int)mad24((uint32_t)(czi - LOz), (uint32_t)SS, mad24((uint32_t)(cyi - LOy), (uint32_t)RS, (uint32_t)(cxi - LOx)));
-      const float* tp = tile + off;
-      const float* tq = tp + SS;                  // slice z + 1
+      // byte address of the sample's cell in the tile: (z * SS + y * RS + x) * 4 + tile_base, the products exact in
+      // fp32 (cells are integers below 2^13, the strides below 2^9).  A lane that does not step (its pending sample
+      // lies outside this window) reads the tile's first cell instead: every read stays inside the wave's tile.
+      const int cell = (int)fma_(flz, (float)SS, fma_(fly, (float)RS, flx));
+      const int addr = go ? (cell << 2) + tile_base : tile_addr;
+      const LdsFloatPtr tp = (LdsFloatPtr)(uintptr_t)(uint32_t)addr;
+      const LdsFloatPtr tq = tp + SS;             // slice z + 1
       const float v000 = tp[0], v100 = tp[1], v010 = tp[RS], v110 = tp[RS + 1];
       const float v001 = tq[0], v101 = tq[1], v011 = tq[RS], v111 = tq[RS + 1];
       n_reads += 4u;
@@ -408,9 +450,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(PHONG ? (SK
       const float d = scale * fma_(mh, fz, ml * wz);
       const float dn = d * inv_maj;
       // A7 / A12 only where they can matter: a sample outside the sample range, or whose TF entry has alpha 0, leaves
-      // tau, T and C exactly as they are (fma(0, dt, tau) == tau, a colour increment of 0), and on this kind of data most
-      // wave steps have no lane inside the range at all (config 3: 82 %), so the LUT fetch, the classification and
-      // the composite sit behind one wave-uniform branch -- 22 of the 85 vector instructions of a step
+      // tau, T and C exactly as they are, and on this kind of data most wave steps have no lane inside the range at
+      // all (config 3: 82 %), so the LUT fetch, the classification and the composite sit behind one wave-uniform branch
       const bool in_range = eval & !(dn < sr0 || dn > sr1);
       if (ballot(in_range) != 0ull) {
 #ifdef VX_COUNT_INRANGE   // diagnostic build: skip_steps counts the wave steps that enter this block
@@ -442,8 +483,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(PHONG ? (SK
               const float gy = scale * fma_(fma_(hxp, fy, hx1 * wy), fz, fma_(lxp, fy, lx1 * wy) * wz) -
                                scale * fma_(fma_(hx0, fy, hxm * wy), fz, fma_(lx0, fy, lxm * wy) * wz);
               // z: T(c + ez) mixes slices z+1, z+2 -- the y lerp of slice z+1 is the centre's mh; T(c - ez) reuses ml
-              const float* tzm = tp - SS;
-              const float* tzp = tq + SS;
+              const LdsFloatPtr tzm = tp - SS;
+              const LdsFloatPtr tzp = tq + SS;
               const float zm0 = tzm[0], zm1 = tzm[1], zm2 = tzm[RS], zm3 = tzm[RS + 1];
               const float zp0 = tzp[0], zp1 = tzp[1], zp2 = tzp[RS], zp3 = tzp[RS + 1];
               const float mp = fma_(fma_(zp3, fx, zp2 * wx), fy, fma_(zp1, fx, zp0 * wx) * wy);
@@ -457,7 +498,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(PHONG ? (SK
         // tau += a*maj*dt; C += (T_prev - T) * rgb   (raymarch.glsl:43 / SURVEY A12) -- straight line, as vx_dvr.hpp
         // No select on `contrib`: T is always exp2(-tau * log2 e) of the lane's current tau (1 at tau = 0; a lane that is
         // never sampled again keeps both), so a sample with alpha = 0 -- tau unchanged: fma(0, dt, tau) == tau --
-        // recomputes the same T, dT = T - T = +0 and C += 0 * rgb leaves C as it is
+        // recomputes the same T, dT = T - T = +0 and C += 0 * rgb leaves C as it is (vx_upload_transfer refuses
+        // non-finite entries, so 0 * rgb is 0)
         tau = fma_(alpha * maj, r.dt, tau);
         const float Tn = __builtin_amdgcn_exp2f(tau * -1.4426950408889634f);
         const float dT = T - Tn;
@@ -465,15 +507,19 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(PHONG ? (SK
         Cy = fma_(dT, rgba.y, Cy);
         Cz = fma_(dT, rgba.z, Cz);
         T = Tn;
-        // early ray termination (contrib && tau >= ert): the lane dies (far = -inf); its T stays exp2(-tau log2 e), so
-        // that later steps of the wave leave its C alone, and becomes 0 after the march
+        // early ray termination (contrib && tau >= ert): the ray has no further samples (nray = -1, klim = 0); its T
+        // stays exp2(-tau log2 e), so that nothing later in the march touches its C, and becomes 0 after the march
         const bool done = contrib && (tau >= ert);
-        far = done ? -__builtin_inff() : far;
+        nray = done ? -1.0f : nray;
+        klim = done ? 0.0f : klim;
       }
-      // the lanes that stepped move on to their next sample
+      // the lanes that stepped move on to their next sample (the others recompute the position they already hold)
       kf = go ? kf + 1.0f + jump : kf;
       next_sample();
-    }
+      ++s;
+      go = kf < klim;
+      more = (s < S) & (ballot(go) != 0ull);   // somebody can still step in this window
+    } while (more);
   };
   while (true) {
     if (ballot(is_alive()) == 0ull) break;
@@ -485,9 +531,10 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(PHONG ? (SK
     if (!next_window(live)) break;
   }
 
+  // (kf counts the samples of a lane: without skipping every step it takes evaluates one; a terminated ray stopped at kf)
   if (!SKIP) n_samples = wave_sum((uint32_t)kf);   // kf <= 2^24: exact; lane 0 holds the sum (add_counts reads it there)
-  // a ray that terminated early (hit, yet far = -inf) is opaque: T = 0 (vx_modes.hpp Frame::dvr)
-  if (hit0 && far == -__builtin_inff()) T = 0.0f;
+  // a ray that terminated early is opaque: T = 0 (vx_modes.hpp Frame::dvr)
+  if (nray < 0.0f) T = 0.0f;
   if (in_image) dvr_store(p, v, r, Cx, Cy, Cz, T, weight, slab, si);
   const uint32_t n_px = (uint32_t)__builtin_popcountll(ballot(in_image));
   add_counts(dc, n_samples, n_rays, n_px, n_skipped, n_grads, n_slots, blk, n_loads, n_reads);

@@ -324,35 +324,39 @@ struct Frame {
       to_index(p, ray, ipos, idir);
       float dt = p.dvr_step_voxels / sqrtf(dot3(idir, idir));
       float t0 = fma_(start_offset, dt, near);
-      float tau = 0.0f, kf = 0.0f;
+      float tau = 0.0f;
+      // [build] march contract: n samples, sample k at q = fma(k, dq, q0) in the cell frame
+      const float xq = (far - t0) / dt;
+      const float nf = (xq > 0.0f) ? fminf(ceilf(xq), (float)p.dvr_max_steps) : 0.0f;
+      const V3 dq = v3(dt * idir.x, dt * idir.y, dt * idir.z);
+      const V3 q0 = v3(fma_(t0, idir.x, ipos.x) - 0.5f, fma_(t0, idir.y, ipos.y) - 0.5f, fma_(t0, idir.z, ipos.z) - 0.5f);
       V3 nl = v3(-p.light_dir[0], -p.light_dir[1], -p.light_dir[2]);
       V3 hv = v3(0, 0, 0);
       if (PHONG) hv = normalize3(sub3(nl, ray.d));
-      for (int i = 0; i < p.dvr_max_steps; ++i, kf += 1.0f) {
-        float t = fma_(kf, dt, t0);
-        if (!(t < far)) break;
-        V3 ip = madd3(ipos, t, idir);
+      for (float kf = 0.0f; kf < nf; kf += 1.0f) {
+        const float qx = fma_(kf, dq.x, q0.x), qy = fma_(kf, dq.y, q0.y), qz = fma_(kf, dq.z, q0.z);
+        const float flx = floorf(qx), fly = floorf(qy), flz = floorf(qz);
+        const float fx = qx - flx, fy = qy - fly, fz = qz - flz;
+        const int cx = f2i(flx), cy = f2i(fly), cz = f2i(flz);
         if (p.dvr_skip_empty && v.skip_bits) {  // exact skipping: alpha would be exactly 0
-          int cx = f2i(floorf(ip.x - 0.5f)) + 1, cy = f2i(floorf(ip.y - 0.5f)) + 1, cz = f2i(floorf(ip.z - 0.5f)) + 1;
+          const int mx = cx + 1, my = cy + 1, mz = cz + 1;
           uint32_t sh = 3u + v.skip_level;
-          if (cx >= 0 && cy >= 0 && cz >= 0 && ((uint32_t)cx >> sh) < v.skip_dims[0] &&
-              ((uint32_t)cy >> sh) < v.skip_dims[1] && ((uint32_t)cz >> sh) < v.skip_dims[2] &&
-              skip_test(v.skip_bits, sh, v.skip_dims[0], v.skip_dims[1], (uint32_t)cx, (uint32_t)cy, (uint32_t)cz)) {
+          if (mx >= 0 && my >= 0 && mz >= 0 && ((uint32_t)mx >> sh) < v.skip_dims[0] &&
+              ((uint32_t)my >> sh) < v.skip_dims[1] && ((uint32_t)mz >> sh) < v.skip_dims[2] &&
+              skip_test(v.skip_bits, sh, v.skip_dims[0], v.skip_dims[1], (uint32_t)mx, (uint32_t)my, (uint32_t)mz)) {
             c.skips++;
             continue;
           }
         }
-        float4 rgba = transfer(trilinear(ip) * p.volume_inv_maj);
+        // lookup_density_trilinear, common.glsl:61-69, from the cell and fractions of q
+        const float dens = trilinear_cell<LAYOUT>(v, p.volume_density_scale, cx, cy, cz, fx, fy, fz);
+        float4 rgba = transfer(dens * p.volume_inv_maj);
         c.samples++;
         if (rgba.w > 0.0f) {
           if (PHONG) {
             c.grads++;
             // [build] central differences one voxel either side, in the sample's own cell frame (cells c +- e, the
             // sample's fractions): DESIGN.md section 2
-            float qx = ip.x - 0.5f, qy = ip.y - 0.5f, qz = ip.z - 0.5f;
-            float flx = floorf(qx), fly = floorf(qy), flz = floorf(qz);
-            float fx = qx - flx, fy = qy - fly, fz = qz - flz;
-            int cx = f2i(flx), cy = f2i(fly), cz = f2i(flz);
             const float ds = p.volume_density_scale;
             float gx = trilinear_cell<LAYOUT>(v, ds, cx + 1, cy, cz, fx, fy, fz) - trilinear_cell<LAYOUT>(v, ds, cx - 1, cy, cz, fx, fy, fz);
             float gy = trilinear_cell<LAYOUT>(v, ds, cx, cy + 1, cz, fx, fy, fz) - trilinear_cell<LAYOUT>(v, ds, cx, cy - 1, cz, fx, fy, fz);
