@@ -14,16 +14,19 @@ of the slab so that it overlaps the next frames.  Strong scaling: the frame is f
 of all ranks / max-over-ranks time.
 
 Prints ONE JSON line on rank 0 (contract in the task statement).  Besides the contract keys:
-  roofline      the dominant kernel (vx::render_dvr_lds<16>; --layout 1: vx::render_dvr_cq<4>): ALGORITHMIC bytes of the launches actually
-                timed (16 B per sample, SURVEY 8(d), + 16 B per pixel per frame for the result the kernel
-                writes) / their mean HIP-event duration, against the 8 TB/s HBM peak; `traffic` = HBM bytes
-                per launch from the rocprofv3 PMC passes of this same command when profiles/traffic.json
-                holds them for exactly this launch shape, else null; `blend` = the merge kernel
-                (fragment.frag:158 applied in order), timed apart; `frames_per_launch_1` = the same
-                measurement with one frame per launch;
-  roofline.issue  the limiter the counters name for the shipped LDS-window kernel: vector-ALU issue -- clocks per wave
-                step per CU (live) against VALU instructions per wave step (rocprofv3) x the device's measured clocks per
-                instruction (vx_probe_valu_rate, this run);
+  roofline      the dominant kernel (vx::render_dvr_lds<16>; --layout 1: vx::render_dvr_cq<4>) against the resource the
+                counters name as its limit.  The LDS-window kernel is bound by vector-ALU issue (`bound` "valu"): `achieved` =
+                the vector instructions the march NEEDS (a hand-derived minimum per sample, NECESSARY_VALU below / DESIGN.md
+                section 6, x the samples and transfer-function fetches the kernel counted) / the mean HIP-event duration of
+                the timed launches; `peak` = one wave64 instruction per 2 clocks per SIMD x 1024 SIMDs at the nominal clock;
+                `frac` = achieved / peak.  `algorithmic_gbs` = the SURVEY 8(d) byte model (16 B per sample + the result
+                written) over the same duration -- NOT a roofline fraction: the kernel stages each voxel once per window, so
+                the model exceeds what the HBM pins carry (`hbm_measured`, `traffic` = HBM bytes per launch from the rocprofv3
+                PMC passes of this same command when profiles/traffic.json holds them for exactly this launch shape, else
+                null); `blend` = the merge kernel (fragment.frag:158 applied in order), timed apart; `frames_per_launch_1` =
+                the same measurement with one frame per launch;
+  roofline.issue  the same limiter from the instructions the kernel actually issued: clocks per wave step per CU (live) against
+                VALU instructions per wave step (rocprofv3 SQ_INSTS_VALU of this same command);
   roofline.l1   (--layout 1, the cellquad gather kernel) the vector L1 / texture path: gather instructions counted by
                 the kernel, distinct 128-byte lines per gather counted by a probe build of the same kernel,
                 clocks per gather per CU, and the floor the L1 sustains for that many line look-ups with no
@@ -167,6 +170,17 @@ def l1_block(r, c, clock_khz_hint=None):
 
 
 VALU_CLK_PER_INST = 2.0   # MI355X_MICROARCH.md: a wave64 VALU instruction issues over 2 cycles of a SIMD-32
+NOMINAL_CLOCK_GHZ = 2.4   # MI355X_MICROARCH.md: max clock 2400 MHz
+N_SIMDS = 1024            # 256 CUs x 4 SIMDs
+# Vector instructions the bit-exact march cannot do without, per sample and lane (DESIGN.md section 6 derives them):
+#   position q = fma(k, dq, q0) per axis 3, floor 3, fraction 3, complement 1 - f 3, tile address 4 (two fmas on the float
+#   cells, one conversion, one shift-add), the seven lerps of common.glsl:62-68 as mul + fma 14, density scale and
+#   inv_maj 2, sample-range test 2, step count 1                                                          = 35
+# and per sample that lies inside the sample range (fetches a transfer-function entry and is composited):
+#   LUT index 3 (mul, convert, clamp), address 1, alpha * maj 1, tau fma 1, exp2 argument 1, exp2 1, T_prev - T 1,
+#   three colour fmas 3, termination test 1                                                               = 13
+NECESSARY_VALU = {"per_sample": 35, "per_tf_sample": 13,
+                  "phong_per_shaded_sample": 0}   # (the Phong gradient is not part of the headline workload)
 
 
 def issue_block(r, c, entry):
@@ -237,6 +251,7 @@ def main():
                     help="keep the device busy with untimed frames of the same workload for this long before the W warm-up "
                          "steps, so that the timed region runs at the clock the chip sustains (an MI355X drops its clocks within "
                          "a millisecond of idling: tools/fpl_sweep.py --sync); 0 = off; reported as config.preconditioning")
+    ap.add_argument("--no-cold", action="store_true", help="skip the un-preconditioned pass that yields value_cold")
     ap.add_argument("--no-jitter", action="store_true",
                     help="diagnostic: pixel-centre rays, identical in every frame (NOT the reference's behaviour)")
     ap.add_argument("--no-skip-variant", action="store_true", help="do not run the secondary measurement with skipping")
@@ -323,16 +338,15 @@ def main():
             state["gathers"] += 1
 
     def fence():
+        """barrier + device synchronisation (the contract's bracket): ONE device-wide synchronisation -- it covers the
+        library's render stream, the communication stream and the pending all_gather -- then the barrier"""
         tt = [time.perf_counter()]
-        r.finish(); tt.append(time.perf_counter())
         if state["work"] is not None:
-            state["work"].wait()
+            state["work"].wait()              # orders the current stream behind the collective (no host wait)
         torch.cuda.synchronize(); tt.append(time.perf_counter())
         if use_dist:
-            dist.barrier(device_ids=[local])
+            dist.barrier(device_ids=[local])  # returns when every rank has arrived (it synchronises its own stream)
         tt.append(time.perf_counter())
-        r.finish()
-        torch.cuda.synchronize(); tt.append(time.perf_counter())
         if os.environ.get("VX_BENCH_TRACE"):
             sys.stderr.write("fence: " + " ".join(f"{(b - a) * 1e3:.3f}" for a, b in zip(tt, tt[1:])) + " ms\n")
 
@@ -350,6 +364,43 @@ def main():
         # RCCL's first barrier sets the collective up (12 ms measured): here, not in the fence before the timed region,
         # where it would leave the device idle
         dist.barrier(device_ids=[local])
+
+    def timed(first):
+        """W untimed warm-up steps, then EXACTLY a.steps accumulation frames between two fences"""
+        # the first two frames (re)build the launch order; the warm-up also performs one gather, so that RCCL's
+        # first-use setup of the collective is not inside the timed region
+        run(first, max(a.warmup, 2), need_image=True)
+        fence()
+        r.reset_counters()
+        t0 = time.perf_counter()
+        run(first + max(a.warmup, 2), a.steps, need_image=True)
+        fence()
+        dt = time.perf_counter() - t0
+        if use_dist:
+            t = torch.tensor([dt], dtype=torch.float64, device="cuda")
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            dt = float(t.item())
+        return dt, r.counters()
+
+    # (1) COLD: the device as the host left it after generating and uploading the volume (clocks down): `value_cold`
+    cold = None
+    if a.precondition_ms > 0 and not a.no_cold:
+        cold_elapsed, cold_c = timed(0)
+        cold = {"elapsed": cold_elapsed, "samples": cold_c.samples}
+        r.restart_rendering()
+        r.bind_uniforms()
+    # (2) the fixed cost of a timed region that renders nothing: snapshot copy + all_gather + the fences
+    fixed_ms = None
+    if use_dist:
+        fence()
+        tf0 = time.perf_counter()
+        gather()
+        fence()
+        fixed_ms = (time.perf_counter() - tf0) * 1e3
+        if use_dist:
+            t = torch.tensor([fixed_ms], dtype=torch.float64, device="cuda")
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            fixed_ms = float(t.item())
     # device preconditioning: the chip idled while the host generated the volume; a few ms of warm-up steps do not
     # bring it back to the clock it sustains under load (measured: 0.36 instead of 0.31 ms per frame)
     pre = {"frames": 0, "seconds": 0.0}
@@ -363,25 +414,14 @@ def main():
         r.restart_rendering()
         r.bind_uniforms()
 
-    # the first two frames (re)build the launch order; the warm-up also performs one gather, so that RCCL's
-    # first-use setup of the collective is not inside the timed region
-    run(0, max(a.warmup, 2), need_image=True)
-    fence()
-    r.reset_counters()
-    t0 = time.perf_counter()
-    run(max(a.warmup, 2), a.steps, need_image=True)      # EXACTLY a.steps accumulation frames
-    fence()
-    elapsed = time.perf_counter() - t0
-    c = r.counters()
+    elapsed, c = timed(0)
 
     samples, pixels = c.samples, c.pixels
+    cold_samples = cold["samples"] if cold else 0
     if use_dist:
-        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
-        s = torch.tensor([samples, pixels], dtype=torch.float64, device="cuda")
+        s = torch.tensor([samples, pixels, cold_samples], dtype=torch.float64, device="cuda")
         dist.all_reduce(s, op=dist.ReduceOp.SUM)
-        samples, pixels = int(s[0].item()), int(s[1].item())
+        samples, pixels, cold_samples = int(s[0].item()), int(s[1].item()), int(s[2].item())
     if use_dist and state["gathers"]:
         # de-tile the last gathered framebuffer so that the image is materialised
         r.detile(gathered.data_ptr(), image.data_ptr())
@@ -398,12 +438,25 @@ def main():
         fpl = int(c.max_launch_frames)
         prof = traffic_from_profile(a, fpl, r.settings.dvr_jitter)
         prof_entry = prof.pop("_entry", None)
+        # the limiter: vector-ALU issue for the LDS-window kernel (rocprofv3: VALU issue ~0.78 of the kernel's clocks, HBM
+        # ~0.1 of peak); for the cellquad gather kernel the L1 tag pipe, detailed in roofline.l1 (its top-level figures
+        # use the same necessary-instruction count, which does not bind that kernel)
+        need = (c.samples * NECESSARY_VALU["per_sample"] + c.tf_samples * NECESSARY_VALU["per_tf_sample"]) / 64.0 / launches
+        valu_peak = N_SIMDS * NOMINAL_CLOCK_GHZ / VALU_CLK_PER_INST            # G wave64 instructions per second
+        valu_achieved = need / avg_kernel_s / 1e9 if avg_kernel_s > 0 else 0.0
         roof = {
-            "bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-            "frac": round(achieved / HBM_PEAK_GBS, 4),
-            "frac_note": ("above 1: the byte model of SURVEY 8(d) charges every sample its own 16 bytes; the kernel stages each "
-                          "voxel once per window and neighbouring samples share taps, so the HBM pins carry far less (traffic / "
-                          "hbm_measured) -- the limiter is the one in roofline.issue / roofline.l1") if achieved > HBM_PEAK_GBS else None,
+            "bound": "valu" if a.layout in (None, 2) else ("l1" if a.layout == 1 else "latency"),
+            "achieved": round(valu_achieved, 1), "peak": round(valu_peak, 1), "unit": "G wave64 VALU instructions/s",
+            "frac": round(valu_achieved / valu_peak, 4),
+            "frac_note": "necessary vector instructions (hand-derived minimum of the bit-exact march: 35 per sample and lane + 13 "
+                         "per sample inside the sample range, / 64 lanes; per-ray set-up, window placement and idle lanes are "
+                         "NOT counted as necessary) per launch / kernel time, against 1024 SIMDs x 2.4 GHz / 2 clocks per instruction",
+            "necessary_valu_per_launch": int(need), "necessary_model": NECESSARY_VALU,
+            "tf_samples_per_frame": int(c.tf_samples // max(c.frames, 1)),
+            "algorithmic_gbs": round(achieved, 1),
+            "algorithmic_gbs_note": "SURVEY 8(d) byte model / kernel time; exceeds the 8000 GB/s HBM peak because the kernel stages "
+                                    "each voxel once per window and neighbouring samples share taps -- kept for comparison with "
+                                    "earlier rounds, not a roofline fraction",
             **prof,
             "kernel": KERNEL[a.layout],
             "avg_kernel_ms": round(c.kernel_ms / launches, 4), "launches": int(c.launches), "frames": int(c.frames),
@@ -425,6 +478,7 @@ def main():
         out = {
             "metric": "Gsamples/s raymarch @512^3 vol, 1080p; achieved HBM GB/s vs peak, 1/2/4/8 GPU",
             "value": round(samples / elapsed / 1e9, 3),
+            "value_cold": round(cold_samples / cold["elapsed"] / 1e9, 3) if cold else None,
             "unit": "Gsamples/s",
             "n_gpus": world,
             "steps": a.steps,
@@ -451,7 +505,10 @@ def main():
                 "frames_per_launch": fpl, "frames_per_launch_requested": P,
                 "timed_region_s": round(elapsed, 4),
                 "preconditioning": {**pre, "note": "untimed frames of the same workload before the warm-up steps: the timed "
-                                    "region then runs at the clock the chip sustains under load (--precondition-ms 0: off)"},
+                                    "region then runs at the clock the chip sustains under load (--precondition-ms 0: off); "
+                                    "value_cold = the same W + K steps measured BEFORE it, on the device as the host-side "
+                                    "volume generation left it"},
+                "fixed_overhead_ms": round(fixed_ms, 3) if fixed_ms is not None else None,
                 "lane_utilisation": round(c.samples / c.lane_slots, 4) if c.lane_slots else None,
                 "device": name, "cus": cus, **info,
             },
@@ -469,7 +526,11 @@ def main():
             roof["frames_per_launch_1"] = {
                 "frames": int(c1.frames), "launches": int(c1.launches), "avg_kernel_ms": round(k1 * 1e3, 4),
                 "gsamples_per_s_kernel_only": round(c1.samples / (c1.kernel_ms / 1e3) / 1e9, 3),
-                "achieved": round(alg1 / k1 / 1e9, 1), "frac": round(alg1 / k1 / 1e9 / HBM_PEAK_GBS, 4),
+                "achieved": round((c1.samples * NECESSARY_VALU["per_sample"] + c1.tf_samples * NECESSARY_VALU["per_tf_sample"])
+                                  / 64.0 / max(c1.launches, 1) / k1 / 1e9, 1),
+                "frac": round((c1.samples * NECESSARY_VALU["per_sample"] + c1.tf_samples * NECESSARY_VALU["per_tf_sample"])
+                              / 64.0 / max(c1.launches, 1) / k1 / 1e9 / valu_peak, 4),
+                "algorithmic_gbs": round(alg1 / k1 / 1e9, 1),
                 "algorithmic_model": "16 B/sample + 32 B/pixel/frame (accumulator read + write in the same kernel)"}
             # (2) the limiter the counters name
             if a.layout == 1:

@@ -151,6 +151,8 @@ typedef struct VxCounters {
                             follow multi-frame launches (fragment.frag:158 applied in order)  */
   uint32_t min_launch_frames; /* smallest / largest number of accumulation frames one launch  */
   uint32_t max_launch_frames; /* actually covered (what ran, not what was requested)           */
+  uint64_t tf_samples;   /* samples whose density lay inside the sample range: the ones that fetch a
+                            transfer-function entry (common.glsl:78-83) and enter the composite  */
 } VxCounters;
 
 typedef struct VxContext VxContext;

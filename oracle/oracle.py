@@ -97,7 +97,7 @@ class Environment:
 
 class VxoCounters(C.Structure):
     _fields_ = [("samples", C.c_uint64), ("rays", C.c_uint64), ("pixels", C.c_uint64),
-                ("skip_steps", C.c_uint64), ("grad_samples", C.c_uint64)]
+                ("skip_steps", C.c_uint64), ("grad_samples", C.c_uint64), ("tf_samples", C.c_uint64)]
 
 
 def _has_fma():

@@ -525,7 +525,9 @@ static float lookup_density_stochastic(Ctx* k, v3 ipos, uint32_t s[4]) {
   /* lookup_density(vec3(tap)): floor of an integer-valued float is itself */
   return k->p->volume_density_scale * vxo_lookup_density_brick(k->v, tap[0], tap[1], tap[2]);
 }
+/* the transfer function of a SAMPLE (counted: tf_samples = samples inside the sample range) */
 static inline void lookup_transfer(Ctx* k, float d, float out[4]) {
+  if (!(d < k->p->sample_range[0] || d > k->p->sample_range[1])) k->c.tf_samples++;
   vxo_lookup_transfer(k->tf, k->tf_len, k->p->sample_range, d, out);
 }
 static inline float trilinear(Ctx* k, v3 ip) {
@@ -629,7 +631,7 @@ static float step_dda(v3 pos, v3 inv_dir, int32_t mip) {
 static inline float local_majorant(Ctx* k, v3 curr, int32_t mip) {
   float rgba[4];
   float m = vxo_lookup_majorant(k->v, k->p->volume_density_scale, curr.x, curr.y, curr.z, mip);
-  lookup_transfer(k, m * k->p->volume_inv_maj, rgba);
+  vxo_lookup_transfer(k->tf, k->tf_len, k->p->sample_range, m * k->p->volume_inv_maj, rgba);   /* a majorant, not a sample */
   return k->p->volume_maj * rgba[3];
 }
 

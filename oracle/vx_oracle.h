@@ -42,6 +42,7 @@ typedef struct VxoCounters {
   uint64_t pixels;
   uint64_t skip_steps;
   uint64_t grad_samples;
+  uint64_t tf_samples;   /* samples whose density lay inside the sample range (common.glsl:79 not taken) */
 } VxoCounters;
 
 /* ---- RNG (shaders/random.glsl) ---- */

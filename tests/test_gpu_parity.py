@@ -274,7 +274,7 @@ def test_config1_sphere_256_live_oracle(oracle):
             img = _render_with_params(r, p)
             c = r.counters()
             assert np.abs(img - want).max() <= 2e-6
-            assert c.samples == oc.samples and c.rays == oc.rays
+            assert c.samples == oc.samples and c.rays == oc.rays and c.tf_samples == oc.tf_samples
 
 
 def test_config1_sphere_256_ortho_live_oracle(oracle):
@@ -294,7 +294,7 @@ def test_config1_sphere_256_ortho_live_oracle(oracle):
             img = _render_with_params(r, p, frame=frame)
             c = r.counters()
             assert np.abs(img - want).max() <= 2e-6
-            assert c.samples == oc.samples and c.rays == oc.rays
+            assert c.samples == oc.samples and c.rays == oc.rays and c.tf_samples == oc.tf_samples
             r.close()
     # the host class binds the same block (Camera.ortho_half_height)
     from volxel_amd import Volxel3DRenderer
@@ -678,7 +678,7 @@ def test_edge_cases_match_oracle(oracle, case):
         c = r.counters()
         assert img.shape == (h, w, 4)
         assert np.abs(img - want).max() <= 2e-6, (case, layout)
-        assert (c.samples, c.rays, c.pixels) == (oc.samples, oc.rays, w * h), (case, layout)
+        assert (c.samples, c.rays, c.pixels, c.tf_samples) == (oc.samples, oc.rays, w * h, oc.tf_samples), (case, layout)
     s, cam, vol, ds, p = make_scene(g, w, h, "no_dda", **{k: v for k, v in kw.items() if not k.startswith("dvr_")})
     want, oc = oracle.render(p, g, tf, L, frame_index=1)
     r = _renderer(g, tf, L, p, 1)
@@ -891,7 +891,7 @@ def test_fullsize_config3_config4_match_live_oracle(big_scene, oracle, mode):
         # the colour sums drift apart by a few 1e-6 (small cases: 2e-6) -- a tenth of BASELINE.md's 1e-4 budget
         tol = 2e-5 if mode == "dvr_phong" else 1e-5
         assert float(np.abs(img - want).max()) <= tol
-        assert (c.samples, c.rays, c.pixels) == (oc.samples, oc.rays, 1920 * 1080)
+        assert (c.samples, c.rays, c.pixels, c.tf_samples) == (oc.samples, oc.rays, 1920 * 1080, oc.tf_samples)
         assert c.samples > (1.4e8 if r.settings.dvr_skip_empty else 2.1e8)
         if mode == "dvr_phong":
             assert c.grad_samples == oc.grad_samples and c.grad_samples > 1e7
@@ -932,7 +932,7 @@ def test_fullsize_config2_ct_phantom_matches_live_oracle(oracle):
         img = r.read_accum(); c = r.counters()
         want, oc = oracle.render(p, vol, *r._tf, frame_index=2, threads=16, env=_oracle_env(oracle, r))
         assert float(np.abs(img - want).max()) <= 1e-5
-        assert (c.samples, c.rays) == (oc.samples, oc.rays)
+        assert (c.samples, c.rays, c.tf_samples) == (oc.samples, oc.rays, oc.tf_samples)
         seen.append((img, c.samples))
     assert np.array_equal(seen[0][0], seen[1][0]) and seen[1][1] < 0.5 * seen[0][1]
     r.close()

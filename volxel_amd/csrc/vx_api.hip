@@ -370,8 +370,8 @@ static int rebuild_skip_mask(VxContext* c) {
 // fold every record array (accumulator slot and pipeline slots) into c->base on the device and zero it
 static int fold_counters(VxContext* c) {
   if (!c->dc || !c->dc_waves) return VX_OK;
-  if (!c->fold_dev) VX_HIP(c, hipMalloc(&c->fold_dev, 8 * sizeof(unsigned long long)));
-  hipLaunchKernelGGL(zero_totals, dim3(1), dim3(8), 0, c->stream, c->fold_dev);
+  if (!c->fold_dev) VX_HIP(c, hipMalloc(&c->fold_dev, 9 * sizeof(unsigned long long)));
+  hipLaunchKernelGGL(zero_totals, dim3(1), dim3(9), 0, c->stream, c->fold_dev);
   auto fold = [&](DevCounters* recs, size_t n) {
     const unsigned blocks = (unsigned)std::min<size_t>((n + 255) / 256, 2048);
     hipLaunchKernelGGL(fold_records, dim3(blocks), dim3(256), 0, c->stream, recs, n, c->fold_dev);
@@ -384,7 +384,7 @@ static int fold_counters(VxContext* c) {
   }
   VX_HIP(c, hipGetLastError());
   VX_HIP(c, hipStreamSynchronize(c->stream));
-  unsigned long long h[8];
+  unsigned long long h[9];
   VX_HIP(c, hipMemcpy(h, c->fold_dev, sizeof h, hipMemcpyDeviceToHost));
   c->base.samples += h[0];
   c->base.lane_slots += h[1];
@@ -394,6 +394,7 @@ static int fold_counters(VxContext* c) {
   c->base.grad_samples += h[5];
   c->base.gathers += h[6];
   c->base.lds_reads += h[7];
+  c->base.tf_samples += h[8];
   return VX_OK;
 }
 
@@ -1461,6 +1462,7 @@ int vx_get_counters(VxContext* c, VxCounters* out) {
   out->merge_ms = c->merge_ms;
   out->min_launch_frames = c->min_launch_frames;
   out->max_launch_frames = c->max_launch_frames;
+  out->tf_samples = c->base.tf_samples;
   return VX_OK;
 }
 

@@ -553,7 +553,7 @@ VXD float sanitize1(float x) { return (x != x || __builtin_isinf(x)) ? 0.0f : x;
 
 // per-wave work counters, flushed with one atomic per wave
 struct Counts {
-  uint32_t samples, rays, skips, grads;
+  uint32_t samples, rays, skips, grads, tf;
 };
 
 }  // namespace vx

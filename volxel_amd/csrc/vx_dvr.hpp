@@ -129,7 +129,7 @@ __global__ __launch_bounds__(256) void render_dvr_cq(const VxParams p, const Dev
   const uint32_t sh = 3u + v.skip_level, md0 = v.skip_dims[0], md1 = v.skip_dims[1];
 
   float Cx = 0.f, Cy = 0.f, Cz = 0.f, T = 1.0f, tau = 0.0f, kf = 0.0f;  // kf: per-lane step index
-  uint32_t n_samples = 0, n_slots = 0, n_skipped = 0, n_batches = 0;    // wave-uniform
+  uint32_t n_samples = 0, n_slots = 0, n_skipped = 0, n_batches = 0, n_tf = 0;    // wave-uniform
   uint32_t spread_wave = 0, spread_quad = 0;                            // PROBE only
 
   while (true) {
@@ -221,6 +221,7 @@ __global__ __launch_bounds__(256) void render_dvr_cq(const VxParams p, const Dev
       // A7: NEAREST LUT, range test
       int ti = med3_i32((int)(dn * lenf), 0, last);  // dn >= 0: truncation == floor
       bool in_range = !(dn < sr0 || dn > sr1);
+      n_tf += (uint32_t)__builtin_popcountll(__ballot(a && in_range));
       float4 rgba = tf_lds[ti];
       float alpha = (a && in_range) ? rgba.w : 0.0f;
       bool contrib = alpha > 0.0f;
@@ -256,7 +257,7 @@ __global__ __launch_bounds__(256) void render_dvr_cq(const VxParams p, const Dev
   }
   if (in_image) dvr_store(p, v, r, Cx, Cy, Cz, T, weight, slab, si);
   const uint32_t n_px = (uint32_t)__builtin_popcountll(__ballot(in_image));
-  add_counts(dc, n_samples, n_rays, n_px, n_skipped, 0u, n_slots, blk, n_batches * (uint32_t)(2 * U));
+  add_counts(dc, n_samples, n_rays, n_px, n_skipped, 0u, n_slots, blk, n_batches * (uint32_t)(2 * U), 0u, n_tf);
 }
 
 VXD int wave_min_i32(int v) {
@@ -349,7 +350,7 @@ __global__ __launch_bounds__(256) void render_dvr_dp(const VxParams p, const Dev
   float Cx = 0.f, Cy = 0.f, Cz = 0.f;   // per-lane partial colour sums
   float carry = 0.0f;                    // optical depth of the ray before this iteration's 8 steps
   float kb = 0.0f;                       // wave-uniform base step of the iteration
-  uint32_t n_samples = 0, n_slots = 0, n_skipped = 0;
+  uint32_t n_samples = 0, n_slots = 0, n_skipped = 0, n_tf = 0;
 
   while (true) {
     {
@@ -409,6 +410,7 @@ __global__ __launch_bounds__(256) void render_dvr_dp(const VxParams p, const Dev
     {
       unsigned long long m = __ballot(valid);
       n_samples += (uint32_t)__builtin_popcountll(m);
+      n_tf += (uint32_t)__builtin_popcountll(__ballot(valid && in_range));
       n_slots += m ? 64u : 0u;
       if (SKIP) n_skipped += (uint32_t)__builtin_popcountll(__ballot(in && empty && (tau_prev < ert)));
     }
@@ -461,7 +463,7 @@ __global__ __launch_bounds__(256) void render_dvr_dp(const VxParams p, const Dev
     dvr_store(p, v, r, Cx, Cy, Cz, T, weight, slab, si);
   }
   const uint32_t n_px = (uint32_t)__builtin_popcountll(__ballot(writer));
-  add_counts(dc, n_samples, n_rays, n_px, n_skipped, 0u, n_slots);
+  add_counts(dc, n_samples, n_rays, n_px, n_skipped, 0u, n_slots, 0xffffffffu, 0u, 0u, n_tf);
 }
 
 inline void launch_dvr_cq_multi(const VxParams& p, const DevVolume& v, const float4* tf, uint32_t tf_len,

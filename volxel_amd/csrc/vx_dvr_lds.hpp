@@ -82,6 +82,23 @@ VXD int wave_minmax(int v) {
   return __builtin_amdgcn_readlane(v, 63);
 }
 
+// three minima at once, the stages of the three chains interleaved: a DPP instruction must wait two cycles for the
+// instruction that wrote its source, and three independent chains fill those slots with work instead of s_nop
+VXD void wave_min3(int& a, int& b, int& c) {
+  constexpr int ID = 0x7fffffff;
+  auto mn = [](int x, int y) { return x < y ? x : y; };
+#define VX_STAGE(CTRL, RM)                              \
+  {                                                     \
+    const int ta = dpp_src<CTRL, RM, 0xf>(ID, a), tb = dpp_src<CTRL, RM, 0xf>(ID, b), tc = dpp_src<CTRL, RM, 0xf>(ID, c); \
+    a = mn(a, ta); b = mn(b, tb); c = mn(c, tc);        \
+  }
+  VX_STAGE(0x111, 0xf) VX_STAGE(0x112, 0xf) VX_STAGE(0x114, 0xf) VX_STAGE(0x118, 0xf) VX_STAGE(0x142, 0xa) VX_STAGE(0x143, 0xc)
+#undef VX_STAGE
+  a = __builtin_amdgcn_readlane(a, 63);
+  b = __builtin_amdgcn_readlane(b, 63);
+  c = __builtin_amdgcn_readlane(c, 63);
+}
+
 // one trilinear mix of eight taps, common.glsl:62-68 (without the density scale)
 VXD float mix8(float v000, float v100, float v010, float v110, float v001, float v101, float v011, float v111,
                float fx, float wx, float fy, float wy, float fz, float wz) {
@@ -171,7 +188,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(PHONG ? (SK
   const float ivz = r.dq.z != 0.0f ? __builtin_amdgcn_rcpf(r.dq.z) : 3.0e38f;
 
   float Cx = 0.f, Cy = 0.f, Cz = 0.f, T = 1.0f, tau = 0.0f, kf = 0.0f;   // kf: per-lane step index
-  uint32_t n_samples = 0, n_slots = 0, n_skipped = 0, n_grads = 0, n_loads = 0, n_reads = 0;   // wave-uniform
+  uint32_t n_samples = 0, n_slots = 0, n_skipped = 0, n_grads = 0, n_loads = 0, n_reads = 0, n_tf = 0;   // wave-uniform
 
   // cell-frame position of the lane's next sample and its floor (the cell), as floats: the march needs no integer
   // cell -- the tile offset is formed in floating point (exact: small integers) and converted once
@@ -203,9 +220,10 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(PHONG ? (SK
   // x is staged in aligned 16-byte chunks: a forward window starts at or below its anchor cell (round down), a
   // backward window ends at or above it (round up) -- the anchor stays inside, up to 3 columns are unused.
   auto anchor = [&](bool mask, int cx, int cy, int cz, int slack, int& ox, int& oy, int& oz) {
-    const int ex_ = wave_minmax<true>(mask ? (fwx ? cx : -cx) : 0x7fffffff);   // min of c, or -(max of c)
-    const int ey_ = wave_minmax<true>(mask ? (fwy ? cy : -cy) : 0x7fffffff);
-    const int ez_ = wave_minmax<true>(mask ? (fwz ? cz : -cz) : 0x7fffffff);
+    int ex_ = mask ? (fwx ? cx : -cx) : 0x7fffffff;   // min of c, or -(max of c)
+    int ey_ = mask ? (fwy ? cy : -cy) : 0x7fffffff;
+    int ez_ = mask ? (fwz ? cz : -cz) : 0x7fffffff;
+    wave_min3(ex_, ey_, ez_);
     ox = fwx ? ex_ - TL::LO_MARGIN - slack : -ex_ + TL::HI_MARGIN - (DX - 1) + slack;
     oy = fwy ? ey_ - TL::LO_MARGIN - slack : -ey_ + TL::HI_MARGIN - (DY - 1) + slack;
     oz = fwz ? ez_ - TL::LO_MARGIN - slack : -ez_ + TL::HI_MARGIN - (DZ - 1) + slack;
@@ -453,7 +471,9 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(PHONG ? (SK
       // tau, T and C exactly as they are, and on this kind of data most wave steps have no lane inside the range at
       // all (config 3: 82 %), so the LUT fetch, the classification and the composite sit behind one wave-uniform branch
       const bool in_range = eval & !(dn < sr0 || dn > sr1);
-      if (ballot(in_range) != 0ull) {
+      const unsigned long long rm = ballot(in_range);
+      if (rm != 0ull) {
+        n_tf += (uint32_t)__builtin_popcountll(rm);
 #ifdef VX_COUNT_INRANGE   // diagnostic build: skip_steps counts the wave steps that enter this block
         if (!SKIP) n_skipped += 1u;
 #endif
@@ -537,7 +557,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(PHONG ? (SK
   if (nray < 0.0f) T = 0.0f;
   if (in_image) dvr_store(p, v, r, Cx, Cy, Cz, T, weight, slab, si);
   const uint32_t n_px = (uint32_t)__builtin_popcountll(ballot(in_image));
-  add_counts(dc, n_samples, n_rays, n_px, n_skipped, n_grads, n_slots, blk, n_loads, n_reads);
+  add_counts(dc, n_samples, n_rays, n_px, n_skipped, n_grads, n_slots, blk, n_loads, n_reads, n_tf);
 }
 
 inline void launch_dvr_lds(const VxParams& p, const DevVolume& v, const float4* tf, uint32_t tf_len, const MultiOut& mo,

@@ -67,24 +67,24 @@ struct DevCounters {
   uint32_t last_slots;  // lane slots of the most recent launch: the cost fed back to build_order
   uint32_t gathers;     // 16-byte-per-lane gather wave instructions issued (tuned DVR kernels)
   uint32_t lds_reads;   // LDS tap-read wave instructions (LDS-tile kernels)
-  uint32_t pad;
+  uint32_t tf;          // samples inside the sample range (LUT fetched)
 };
 
-__global__ void zero_totals(unsigned long long* sums) { sums[threadIdx.x] = 0ull; }
+__global__ void zero_totals(unsigned long long* sums) { sums[threadIdx.x] = 0ull; }   // 9 totals (fold_records)
 
 // sums the per-wave records of one launch slot into eight 64-bit totals and zeroes them (vx_get_counters /
 // vx_reset_counters: 64 bytes cross PCIe instead of every record)
 __global__ __launch_bounds__(256) void fold_records(DevCounters* __restrict__ recs, size_t n,
                                                     unsigned long long* __restrict__ sums) {
-  unsigned long long s[8] = {0ull, 0ull, 0ull, 0ull, 0ull, 0ull, 0ull, 0ull};
+  unsigned long long s[9] = {0ull, 0ull, 0ull, 0ull, 0ull, 0ull, 0ull, 0ull, 0ull};
   for (size_t i = (size_t)blockIdx.x * 256u + threadIdx.x; i < n; i += (size_t)gridDim.x * 256u) {
     const DevCounters r = recs[i];
     s[0] += r.samples; s[1] += r.slots; s[2] += r.rays; s[3] += r.pixels;
-    s[4] += r.skips; s[5] += r.grads; s[6] += r.gathers; s[7] += r.lds_reads;
+    s[4] += r.skips; s[5] += r.grads; s[6] += r.gathers; s[7] += r.lds_reads; s[8] += r.tf;
     recs[i] = DevCounters{};
   }
 #pragma unroll
-  for (int k = 0; k < 8; ++k) {
+  for (int k = 0; k < 9; ++k) {
     unsigned long long x = s[k];
     for (int off = 32; off > 0; off >>= 1) x += __shfl_xor(x, off);
     if ((threadIdx.x & 63u) == 0u && x != 0ull) atomicAdd(&sums[k], x);
@@ -94,7 +94,7 @@ __global__ __launch_bounds__(256) void fold_records(DevCounters* __restrict__ re
 // `block` = logical block id (identical to blockIdx.x unless the launch is permuted by `order`)
 VXD void add_counts(DevCounters* dc, uint32_t samples, uint32_t rays, uint32_t pixels, uint32_t skips,
                     uint32_t grads, uint32_t slots, uint32_t block = 0xffffffffu, uint32_t gathers = 0u,
-                    uint32_t lds_reads = 0u) {
+                    uint32_t lds_reads = 0u, uint32_t tf = 0u) {
   if ((threadIdx.x & 63u) == 0) {
     if (block == 0xffffffffu) block = blockIdx.x;
     DevCounters* w = dc + (block * (blockDim.x >> 6) + (threadIdx.x >> 6));
@@ -102,6 +102,7 @@ VXD void add_counts(DevCounters* dc, uint32_t samples, uint32_t rays, uint32_t p
     c.last_slots = slots;
     c.gathers += gathers;
     c.lds_reads += lds_reads;
+    c.tf += tf;
     c.samples += samples;
     c.slots += slots;
     c.rays += rays;
@@ -114,8 +115,8 @@ VXD void add_counts(DevCounters* dc, uint32_t samples, uint32_t rays, uint32_t p
 
 VXD void flush_counts(DevCounters* dc, const Counts& c, uint32_t pixels, uint32_t block = 0xffffffffu) {
   uint32_t s = wave_sum(c.samples), r = wave_sum(c.rays), k = wave_sum(c.skips),
-           g = wave_sum(c.grads), px = wave_sum(pixels);
-  add_counts(dc, s, r, px, k, g, 0u, block);
+           g = wave_sum(c.grads), px = wave_sum(pixels), t = wave_sum(c.tf);
+  add_counts(dc, s, r, px, k, g, 0u, block, 0u, 0u, t);
 }
 
 constexpr uint32_t TF_LDS_MAX = 2048;  // entries staged in LDS (32 KiB); longer LUTs stay in L1/L2
@@ -199,7 +200,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(generic_min
   int px, py;
   uint32_t si;
   bool active = wave_pixel(tm, lt, wt, lane, px, py, si);
-  Counts c{0, 0, 0, 0};
+  Counts c{0, 0, 0, 0, 0};
   if (active) {
     Frame<LAYOUT> f{p, v, tf, c};
     float4 r = f.template shade_pixel<MODE>(px, py, frame);
@@ -230,7 +231,7 @@ __global__ __launch_bounds__(64) void probe_tile_costs(const VxParams p, const D
   tf.lenf = (float)tf_len;
   const uint32_t t = blockIdx.x, lane = threadIdx.x & 63u;
   const int px = (int)((t % tm.tiles_x) * 64u + (lane & 7u) * 8u + 4u), py = (int)((t / tm.tiles_x) * 64u + (lane >> 3) * 8u + 4u);
-  Counts c{0, 0, 0, 0};
+  Counts c{0, 0, 0, 0, 0};
   if ((uint32_t)px < tm.W && (uint32_t)py < tm.H) {
     Frame<LAYOUT> f{p, v, tf, c};
     (void)f.template shade_pixel<VX_MODE_DVR>(px, py, 0u);

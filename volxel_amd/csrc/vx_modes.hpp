@@ -13,7 +13,10 @@ struct Frame {
   TfView tf;
   Counts& c;
 
-  VXD float4 transfer(float d) const { return lookup_transfer(tf, p.sample_range[0], p.sample_range[1], d); }
+  VXD float4 transfer(float d) const {
+    if (!(d < p.sample_range[0] || d > p.sample_range[1])) c.tf++;
+    return lookup_transfer(tf, p.sample_range[0], p.sample_range[1], d);
+  }
   VXD float trilinear(V3 ip) const {
     return lookup_density_trilinear<LAYOUT>(v, p.volume_density_scale, ip);
   }

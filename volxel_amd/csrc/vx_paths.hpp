@@ -62,7 +62,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(VX_W_PATHS,
   int px, py;
   uint32_t si;
   const bool in_image = wave_pixel(tm, lt, wt, lane, px, py, si);
-  Counts c{0, 0, 0, 0};
+  Counts c{0, 0, 0, 0, 0};
   Frame<LAYOUT> fr{p, v, tf, c};
 
   // fragment.frag:158 for one finished path: out = w*prev + (1-w)*sanitize(result), alpha 1
