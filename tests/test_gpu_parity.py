@@ -125,6 +125,63 @@ def test_golden_stochastic_modes(oracle, name, layout):
     assert c.rays == int(want["rays"])
 
 
+@pytest.mark.parametrize("mode,env", [("default", False), ("no_dda", False), ("raymarch", False), ("default", True)])
+def test_converged_mean_matches_oracle(oracle, mode, env):
+    """SURVEY.md hard part 1 (iii): besides per-frame agreement the CONVERGED image of a stochastic mode must agree within
+    Monte-Carlo bounds.  256 accumulation frames of a 64x48 scene are accumulated by the viewer's running mean on the
+    device (fragment.frag:155-158 with the weight of viewer.ts:1356: frames 0-4 carry weight 0, frame f >= 5 is
+    blended with w = (f - 5) / (f - 4)) and, frame by frame, by the oracle; per pixel and channel
+    |mean_HIP - mean_oracle| <= 3 sigma / sqrt(N) with sigma the standard deviation of the oracle's per-frame values
+    (+ 2e-6 where sigma is 0: background and fp32 rounding of the recurrence).  A systematic error of the device path
+    -- a biased decision, a wrong weight -- would exceed the bound on many pixels at once; an isolated flipped
+    collision decision (a 1-ulp log) moves a pixel by its sample value / N, far inside it."""
+    from tests.common import make_scene, benchmark_tf, BENCH_CAM, small_noise
+    from volxel_amd import Volxel3DRenderer, sample_weight
+    vox, sp = small_noise(48, seed=3)
+    g = oracle.BrickGrid(vox, sp)
+    tf, L = benchmark_tf()
+    W, H, N, F0 = 64, 48, 256, 5
+    r = Volxel3DRenderer(W, H)
+    r.setup_from_grid(g)
+    r.change_transfer_func(tf, L)
+    r.settings.render_mode, r.settings.bounces = mode, 2
+    r.settings.sample_range = (0.05, 1.0)
+    r.settings.use_env = env
+    r.settings.max_samples = 1 << 20
+    r.camera.pos = np.asarray(BENCH_CAM["cam_pos"], dtype=np.float64)
+    r.camera.view = np.asarray(BENCH_CAM["look_at"], dtype=np.float64)
+    p = r.bind_uniforms()
+    r.restart_rendering(); r.reset_counters()
+    r.render(frames=F0 + N, rebind=False, in_flight=16)      # frames 0 .. F0 + N - 1, blended on the device
+    got = r.read_accum()
+    c = r.counters()
+    oenv = _oracle_env(oracle, r) if env else None
+    frames = np.empty((N, H, W, 3), dtype=np.float32)
+    acc = np.zeros((H, W, 4), dtype=np.float32)
+    n_samples = 0
+    for f in range(F0 + N):
+        img, oc = oracle.render(p, g, tf, L, frame_index=f, env=oenv)
+        n_samples += oc.samples
+        w = np.float32(sample_weight(f))
+        # fragment.frag:158 in fp32, as merge_results applies it: fma(1 - w, result, w * prev)
+        acc[..., :3] = ((np.float32(1) - w) * img[..., :3].astype(np.float64) + (w * acc[..., :3]).astype(np.float64)).astype(np.float32)
+        acc[..., 3] = 1
+        if f >= F0:
+            frames[f - F0] = img[..., :3]
+    mean64 = frames.astype(np.float64).mean(axis=0)
+    sigma = frames.astype(np.float64).std(axis=0)
+    bound = 3.0 * sigma / math.sqrt(N) + 2e-6
+    # the oracle's own recurrence against the plain mean of its frames: the viewer's weights form a running mean
+    assert np.abs(acc[..., :3] - mean64).max() <= 1e-5 * max(1.0, float(mean64.max()))
+    err = np.abs(got[..., :3].astype(np.float64) - mean64)
+    assert (err <= bound).all(), (mode, env, float((err / bound).max()), int((err > bound).sum()))
+    assert float(sigma.max()) > 1e-3                       # the scene is not trivially deterministic
+    assert abs(int(c.samples) - n_samples) <= 0.002 * n_samples + 64
+    print(f"converged mean {mode} env={env}: max err / bound {(err / bound).max():.3f}, max |err| {err.max():.2e}, "
+          f"mean sigma {sigma.mean():.3e}")
+    r.close()
+
+
 # ---- row N3: environment-map lighting (environment.ts, envSetup.frag, environment.glsl) ----------
 @pytest.mark.parametrize("mode,bounces", [("default", 1), ("default", 3), ("no_dda", 2), ("raymarch", 1), ("default", 0)])
 def test_repacked_path_kernel_is_bit_identical(oracle, mode, bounces, monkeypatch):
@@ -222,8 +279,8 @@ def test_golden_environment_stochastic_modes(oracle, name):
     c = r.counters()
     diff = np.abs(img - want["image"]).max(axis=2)
     frac = (diff <= 1e-4).mean()
-    assert frac >= 0.995, (name, frac, diff.max())
-    assert abs(int(c.samples) - int(want["samples"])) <= 0.005 * int(want["samples"]) + 64
+    assert frac >= 0.999, (name, frac, diff.max())
+    assert abs(int(c.samples) - int(want["samples"])) <= 0.002 * int(want["samples"]) + 64
     assert c.rays == int(want["rays"])
 
 
@@ -250,7 +307,7 @@ def test_environment_custom_map_and_errors(oracle):
     oenv = oracle.Environment(env.floats, env.width, env.height)
     want, oc = oracle.render(p, g, tf, L, frame_index=2, env=oenv)
     diff = np.abs(r.read_accum() - want).max(axis=2)
-    assert (diff <= 1e-4).mean() >= 0.995, diff.max()
+    assert (diff <= 1e-4).mean() >= 0.999, diff.max()
     r.set_environment(None)
     assert r.bind_uniforms().use_env == 0          # host falls back to the directional light
     p.use_env = 1
@@ -684,7 +741,7 @@ def test_edge_cases_match_oracle(oracle, case):
     r = _renderer(g, tf, L, p, 1)
     img = _render_with_params(r, p, 1)
     diff = np.abs(img - want).max(axis=2)
-    assert (diff <= 1e-4).mean() >= 0.99, (case, diff.max())
+    assert (diff <= 1e-4).mean() >= 0.999, (case, diff.max())
     assert r.counters().rays == oc.rays
 
 
