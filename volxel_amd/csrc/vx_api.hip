@@ -425,8 +425,9 @@ static int ensure_counters(VxContext* c, size_t waves) {
 }
 
 // The device layout the kernels of the current render mode sample.  VX_LAYOUT_AUTO (default): the DVR modes march
-// the brickf32 layout through LDS windows (vx_dvr_lds.hpp: fastest, 4 bytes per voxel), the path-traced reference
-// modes gather from cellquad (two 16-byte loads per trilinear look-up instead of eight bounds-checked taps).
+// the brickf32 layout through LDS windows (vx_dvr_lds.hpp: fastest, 4 bytes per voxel), `default` and `no_dda`
+// gather from cellquad (two 16-byte loads per trilinear look-up instead of eight bounds-checked taps), `raymarch`
+// reads its single nearest tap from brickf32.
 static int primary_layout(const VxContext* c) {
   if (c->layout != VX_LAYOUT_AUTO) return c->layout;
   return c->auto_no_bf ? VX_LAYOUT_REFERENCE : VX_LAYOUT_BRICKF32;
@@ -434,7 +435,9 @@ static int primary_layout(const VxContext* c) {
 static int eff_layout(const VxContext* c) {
   if (c->layout != VX_LAYOUT_AUTO) return c->layout;
   const int m = c->has_params ? c->params.render_mode : VX_MODE_DVR;
-  if (m == VX_MODE_DVR || m == VX_MODE_DVR_PHONG) return primary_layout(c);
+  // raymarch takes ONE nearest tap per sample (common.glsl:72-76): the 4-byte-per-voxel bricks serve it better than
+  // the 18-byte-per-voxel quads, and the layout is resident already
+  if (m == VX_MODE_DVR || m == VX_MODE_DVR_PHONG || m == VX_MODE_RAYMARCH) return primary_layout(c);
   return c->auto_no_cq ? VX_LAYOUT_REFERENCE : VX_LAYOUT_CELLQUAD;
 }
 

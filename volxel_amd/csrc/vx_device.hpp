@@ -354,9 +354,32 @@ VXD float4 lookup_transfer(const TfView& tf, const float sr0, const float sr1, f
   return tf.lut[i];
 }
 
-// A6: stochastic_tricubic_filter, common.glsl:9-32
+// A7 for a march that only needs the extinction (raymarch.glsl:20-21,41-43 read .a; .rgb only at the collision)
+VXD float lookup_transfer_alpha(const TfView& tf, const float sr0, const float sr1, float d) {
+  int i = f2i(floorf(d * tf.lenf));
+  i = clamp0_i32(i, (int)tf.len - 1);
+  float a;
+  if (tf.in_lds) a = ((LdsFloat4Ptr)tf.lut + i)->w;
+  else a = tf.lut[i].w;
+  return (d < sr0 || d > sr1) ? 0.0f : a;
+}
+
+// A6: stochastic_tricubic_filter, common.glsl:9-32.
+// Each of the nine reservoir decisions is `rng < w / max(1e-3, sum)` with an IEEE quotient (common.glsl:21,25,29).
+// The quotient q = RN(w / m) is only compared with r, a multiple of 2^-24 in [0, 1): with e = r * m - w,
+// |e| > m * 2^-23 means |r - w/m| > 2^-23, more than the 2^-24 by which q can differ from w / m (|w/m| < 2), so
+// (r < q) == (e < 0) -- and d = fma(r, m, -w) is e correctly rounded, same sign, |d| > m * 2^-23 only if |e| is.  One
+// fma, one compare and one band test replace the ten-instruction division sequence; when some lane of the wave falls
+// inside the band (about 3e-7 of the decisions) the stage is re-decided with the quotient itself, so every decision --
+// hence every tap, every sample and the RNG stream -- is the one the reference's expression gives.
+VXD bool reservoir_take(float r, float w, float sum, bool& unsure) {
+  const float m = gl_max(1e-3f, sum);
+  const float d = fma_(r, m, -w);
+  unsure = unsure | !(__builtin_fabsf(d) > m * 1.1920928955078125e-07f);
+  return d < 0.0f;
+}
 VXD void stochastic_tricubic_filter(V3 ipos, Rng& s, int tap[3]) {
-  float q[3] = {ipos.x - 0.5f, ipos.y - 0.5f, ipos.z - 0.5f};
+  const float q[3] = {ipos.x - 0.5f, ipos.y - 0.5f, ipos.z - 0.5f};
   int ii[3], idx[3] = {0, 0, 0};
   float t[3], t2[3], w[3], sum[3], r[3];
   const float sixth = 1.0f / 6.0f;
@@ -368,33 +391,29 @@ VXD void stochastic_tricubic_filter(V3 ipos, Rng& s, int tap[3]) {
     w[c] = sixth * (fma_(-3.0f, t[c], fma_(3.0f, t2[c], -t[c] * t2[c])) + 1.0f);
     sum[c] = w[c];
   }
+  // stage k: weight k (common.glsl:19,23,27), running sum, three draws, three decisions
+  auto stage = [&](int k) {
 #pragma unroll
-  for (int c = 0; c < 3; ++c) {
-    w[c] = sixth * (fma_(-6.0f, t2[c], 3.0f * t[c] * t2[c]) + 4.0f);
-    sum[c] = w[c] + sum[c];
-  }
-  r[0] = rng(s); r[1] = rng(s); r[2] = rng(s);
+    for (int c = 0; c < 3; ++c) {
+      if (k == 1) w[c] = sixth * (fma_(-6.0f, t2[c], 3.0f * t[c] * t2[c]) + 4.0f);
+      else if (k == 2) w[c] = sixth * (fma_(3.0f, t[c], fma_(3.0f, t2[c], -3.0f * t[c] * t2[c])) + 1.0f);
+      else w[c] = sixth * t[c] * t2[c];
+      sum[c] = w[c] + sum[c];
+    }
+    r[0] = rng(s); r[1] = rng(s); r[2] = rng(s);
+    bool unsure = false, take[3];
 #pragma unroll
-  for (int c = 0; c < 3; ++c)
-    if (r[c] < w[c] / gl_max(1e-3f, sum[c])) idx[c] = 1;
+    for (int c = 0; c < 3; ++c) take[c] = reservoir_take(r[c], w[c], sum[c], unsure);
+    if (ballot(unsure) != 0ull) {   // wave uniform, rare: the reference's expression itself
 #pragma unroll
-  for (int c = 0; c < 3; ++c) {
-    w[c] = sixth * (fma_(3.0f, t[c], fma_(3.0f, t2[c], -3.0f * t[c] * t2[c])) + 1.0f);
-    sum[c] = w[c] + sum[c];
-  }
-  r[0] = rng(s); r[1] = rng(s); r[2] = rng(s);
+      for (int c = 0; c < 3; ++c) take[c] = r[c] < w[c] / gl_max(1e-3f, sum[c]);
+    }
 #pragma unroll
-  for (int c = 0; c < 3; ++c)
-    if (r[c] < w[c] / gl_max(1e-3f, sum[c])) idx[c] = 2;
-#pragma unroll
-  for (int c = 0; c < 3; ++c) {
-    w[c] = sixth * t[c] * t2[c];
-    sum[c] = w[c] + sum[c];
-  }
-  r[0] = rng(s); r[1] = rng(s); r[2] = rng(s);
-#pragma unroll
-  for (int c = 0; c < 3; ++c)
-    if (r[c] < w[c] / gl_max(1e-3f, sum[c])) idx[c] = 3;
+    for (int c = 0; c < 3; ++c) idx[c] = take[c] ? k : idx[c];
+  };
+  stage(1);
+  stage(2);
+  stage(3);
 #pragma unroll
   for (int c = 0; c < 3; ++c) tap[c] = ii[c] + idx[c] - 1;
 }

@@ -13,6 +13,10 @@ struct Frame {
   TfView tf;
   Counts& c;
 
+  VXD float transfer_alpha(float d) const {   // the .a of transfer(d), counted the same
+    if (!(d < p.sample_range[0] || d > p.sample_range[1])) c.tf++;
+    return lookup_transfer_alpha(tf, p.sample_range[0], p.sample_range[1], d);
+  }
   VXD float4 transfer(float d) const {
     if (!(d < p.sample_range[0] || d > p.sample_range[1])) c.tf++;
     return lookup_transfer(tf, p.sample_range[0], p.sample_range[1], d);
@@ -39,13 +43,15 @@ struct Frame {
     float dt = (far - near) / 64.0f;
     near = fma_(rng(s), dt, near);
     float tau = 0.0f;
-    for (int i = 0; i < 64; ++i) {
-      float t = gl_min(fma_((float)i, dt, near), far);
+    float kf = 0.0f;
+#pragma unroll 1
+    for (int i = 0; i < 64; ++i, kf += 1.0f) {
+      float t = gl_min(fma_(kf, dt, near), far);
       float d = density_stochastic(madd3(ipos, t, idir), s);
-      float4 rgba = transfer(d * p.volume_inv_maj);
-      tau = fma_(rgba.w * p.volume_maj, dt, tau);
-      c.samples++;
+      float a = transfer_alpha(d * p.volume_inv_maj);
+      tau = fma_(a * p.volume_maj, dt, tau);
     }
+    c.samples += 64u;
     return expf(-tau);
   }
   VXD bool sample_raymarch(const Ray& ray, float& t, V3& thr, Rng& s) const {  // :25-55
@@ -56,20 +62,23 @@ struct Frame {
     float tau_target = -logf(1.0f - rng(s));
     float dt = (far - near) / 64.0f;
     near = fma_(rng(s), dt, near);
-    float tau = 0.0f;
-    for (int i = 0; i < 64; ++i) {
-      t = gl_min(fma_((float)i, dt, near), far);
-      float d = density_stochastic(madd3(ipos, t, idir), s);
-      float4 rgba = transfer(d * p.volume_inv_maj);
-      tau = fma_(rgba.w * p.volume_maj, dt, tau);
-      c.samples++;
+    float tau = 0.0f, kf = 0.0f;
+#pragma unroll 1
+    for (int i = 0; i < 64; ++i, kf += 1.0f) {
+      t = gl_min(fma_(kf, dt, near), far);
+      const float dn = density_stochastic(madd3(ipos, t, idir), s) * p.volume_inv_maj;
+      const float a = transfer_alpha(dn);
+      tau = fma_(a * p.volume_maj, dt, tau);
       if (tau >= tau_target) {
+        c.samples += (uint32_t)i + 1u;
+        const float4 rgba = lookup_transfer(tf, p.sample_range[0], p.sample_range[1], dn);   // the colour, once
         thr.x *= rgba.x * p.volume_albedo[0];
         thr.y *= rgba.y * p.volume_albedo[1];
         thr.z *= rgba.z * p.volume_albedo[2];
         return true;
       }
     }
+    c.samples += 64u;
     return false;
   }
 
