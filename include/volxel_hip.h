@@ -153,6 +153,9 @@ typedef struct VxCounters {
   uint32_t max_launch_frames; /* actually covered (what ran, not what was requested)           */
   uint64_t tf_samples;   /* samples whose density lay inside the sample range: the ones that fetch a
                             transfer-function entry (common.glsl:78-83) and enter the composite  */
+  uint64_t active_lane_slots; /* of lane_slots, the slots whose lane did work -- counted by the event-batched path
+                            kernels (default / no_dda), whose lanes may wait for an event pass; 0 elsewhere
+                            (for the DVR kernels samples / lane_slots is the lane utilisation)          */
 } VxCounters;
 
 typedef struct VxContext VxContext;

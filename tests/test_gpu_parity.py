@@ -195,7 +195,7 @@ def test_repacked_path_kernel_is_bit_identical(oracle, mode, bounces, monkeypatc
     g = oracle.BrickGrid(vox, sp)
     tf, L = benchmark_tf()
     res = {}
-    for kern in ("generic", "packed"):
+    for kern in ("generic", "packed", "events"):     # "events": the shipped default (vx_events.hpp) for default / no_dda
         monkeypatch.setenv("VX_PATHS_KERNEL", kern)
         for layout in (0, 1, 2):
             r = Volxel3DRenderer(200, 136, layout=layout)       # not a multiple of 16: partial workgroups
@@ -212,8 +212,10 @@ def test_repacked_path_kernel_is_bit_identical(oracle, mode, bounces, monkeypatc
             res[(kern, layout)] = (r.read_accum(), c.samples, c.skip_steps, c.rays)
             r.close()
     for layout in (0, 1, 2):
-        a, b = res[("generic", layout)], res[("packed", layout)]
-        assert np.array_equal(a[0], b[0]) and a[1:] == b[1:], (mode, layout)
+        a = res[("generic", layout)]
+        for kern in ("packed", "events"):
+            b = res[(kern, layout)]
+            assert np.array_equal(a[0], b[0]) and a[1:] == b[1:], (mode, bounces, kern, layout)
         assert a[1] > 0 and np.isfinite(a[0]).all()
 
 

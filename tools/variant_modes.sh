@@ -1,12 +1,8 @@
 #!/bin/bash
-# usage (on the GPU box): tools/variant_modes.sh variants/*.so -- tools/mode_bench.py with each library variant
-cp volxel_amd/libvolxel_hip.so /tmp/base.so
-for v in base "$@"; do
-  if [ "$v" != base ]; then cp "$v" volxel_amd/libvolxel_hip.so; else cp /tmp/base.so volxel_amd/libvolxel_hip.so; fi
-  echo "== $v"
-  timeout -k 10 300 python tools/mode_bench.py 2>/dev/null | python -c "
-import sys, json
-for l in sys.stdin:
-    d = json.loads(l); print('  %-50s %.4f ms' % (d['case'], d['ms_per_frame']))"
+# usage (GPU box): tools/variant_modes.sh "<mode_probe args>" name...   -- tools/mode_probe.py with each library variant
+ARGS=$1; shift
+for v in "$@"; do
+  if [ "$v" = default ]; then unset VOLXEL_HIP_LIB; else export VOLXEL_HIP_LIB=$PWD/volxel_amd/libvolxel_hip_$v.so; fi
+  echo "=== $v"
+  timeout -k 10 300 python tools/mode_probe.py $ARGS 2>/dev/null
 done
-cp /tmp/base.so volxel_amd/libvolxel_hip.so

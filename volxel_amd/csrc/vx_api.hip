@@ -15,6 +15,7 @@
 #include "vx_dvr_lds.hpp"
 #include "vx_kernels.hpp"
 #include "vx_paths.hpp"
+#include "vx_events.hpp"
 
 using namespace vx;
 
@@ -108,8 +109,10 @@ struct VxContext {
     max_launch_frames = n > max_launch_frames ? n : max_launch_frames;
   }
   int dvr_variant = -1;  // -1: tuned kernel; 0: generic
-  int paths_variant = 0;   // 0: one pixel per lane (render_generic); 1: path segments re-packed through LDS
-                           // (vx_paths.hpp, VX_PATHS_KERNEL=packed) -- same bits, measured 3-11 % slower
+  int paths_variant = 0;   // 0 / 2: one pixel per lane (render_generic); 1: path segments re-packed through LDS
+                           // (vx_paths.hpp, VX_PATHS_KERNEL=packed) -- same bits, measured 3-11 % slower; 3: the
+                           // wave-persistent event-batched form (vx_events.hpp, VX_PATHS_KERNEL=events) -- same
+                           // bits, denser lanes, measured 1.4-1.8x slower
 
   // frame pipelining (vx_render_frames): independent accumulation frames in flight on their own
   // streams, each into its own result slab + counter records; blended in order afterwards
@@ -122,6 +125,10 @@ struct VxContext {
     bool has_merged = false;
   };
   std::vector<Pipe> pipes;
+  // the result slabs and counter records of all slots are ONE allocation each (slot i at i * pipe_quads /
+  // i * pipe_waves): the event kernel addresses a frame slot by base + stride instead of by a pointer table
+  float4* pipe_result_pool = nullptr;
+  DevCounters* pipe_dc_pool = nullptr;
   size_t pipe_quads = 0, pipe_waves = 0;
   uint32_t pipe_next = 0;
   int dp_env = -1;       // VX_DVR_DP=1: depth-parallel waves (experiment, see vx_dvr.hpp)
@@ -370,8 +377,8 @@ static int rebuild_skip_mask(VxContext* c) {
 // fold every record array (accumulator slot and pipeline slots) into c->base on the device and zero it
 static int fold_counters(VxContext* c) {
   if (!c->dc || !c->dc_waves) return VX_OK;
-  if (!c->fold_dev) VX_HIP(c, hipMalloc(&c->fold_dev, 9 * sizeof(unsigned long long)));
-  hipLaunchKernelGGL(zero_totals, dim3(1), dim3(9), 0, c->stream, c->fold_dev);
+  if (!c->fold_dev) VX_HIP(c, hipMalloc(&c->fold_dev, 10 * sizeof(unsigned long long)));
+  hipLaunchKernelGGL(zero_totals, dim3(1), dim3(10), 0, c->stream, c->fold_dev);
   auto fold = [&](DevCounters* recs, size_t n) {
     const unsigned blocks = (unsigned)std::min<size_t>((n + 255) / 256, 2048);
     hipLaunchKernelGGL(fold_records, dim3(blocks), dim3(256), 0, c->stream, recs, n, c->fold_dev);
@@ -384,7 +391,7 @@ static int fold_counters(VxContext* c) {
   }
   VX_HIP(c, hipGetLastError());
   VX_HIP(c, hipStreamSynchronize(c->stream));
-  unsigned long long h[9];
+  unsigned long long h[10];
   VX_HIP(c, hipMemcpy(h, c->fold_dev, sizeof h, hipMemcpyDeviceToHost));
   c->base.samples += h[0];
   c->base.lane_slots += h[1];
@@ -395,6 +402,7 @@ static int fold_counters(VxContext* c) {
   c->base.gathers += h[6];
   c->base.lds_reads += h[7];
   c->base.tf_samples += h[8];
+  c->base.active_lane_slots += h[9];
   return VX_OK;
 }
 
@@ -472,11 +480,45 @@ static void launch_paths(VxContext* c, const MultiOut& mo, float weight, dim3 gr
                        mo, weight, c->tm);
 }
 
+// default / no_dda as the wave-persistent, event-batched path tracer (vx_events.hpp).  The frame slots of `mo` must be
+// consecutive frames at constant strides (vx_render_frames allocates them that way).
+template <int MODE>
+static void launch_events(VxContext* c, const MultiOut& mo, float weight, dim3 grid, hipStream_t stream) {
+  const uint32_t n = mo.count ? mo.count : 1u;
+  const uint64_t out_stride = n > 1 ? (uint64_t)(mo.out[1] - mo.out[0]) : 0u, dc_stride = n > 1 ? (uint64_t)(mo.dc[1] - mo.dc[0]) : 0u;
+  const uint32_t groups = (n + VX_EV_FRAMES - 1u) / VX_EV_FRAMES;
+  grid.x *= groups;
+  const size_t lds = (size_t)c->tf_len * sizeof(float4) + 4u * PF_COUNT * 64u * sizeof(float);
+  const int lay = eff_layout(c);
+#define VX_LAUNCH_EV(LAY) \
+  hipLaunchKernelGGL((render_events<MODE, LAY>), grid, dim3(256), lds, stream, c->params, c->dv, c->tf, c->tf_len, mo.out[0], \
+                     out_stride, mo.dc[0], dc_stride, mo.frame[0], n, weight, c->tm)
+  if (lay == VX_LAYOUT_BRICKF32) VX_LAUNCH_EV(LAYOUT_BF);
+  else if (lay == VX_LAYOUT_CELLQUAD) VX_LAUNCH_EV(LAYOUT_CQ);
+  else VX_LAUNCH_EV(LAYOUT_REF);
+#undef VX_LAUNCH_EV
+}
+static bool events_possible(const VxContext* c, const MultiOut& mo) {
+  if (c->paths_variant != 3 || c->params.debug_hits || c->tf_len > TF_LDS_MAX) return false;
+  if (c->params.render_mode != VX_MODE_DEFAULT && c->params.render_mode != VX_MODE_NO_DDA) return false;
+  const uint32_t n = mo.count ? mo.count : 1u;
+  for (uint32_t i = 1; i < n; ++i)   // consecutive frames, constant strides, slab slots below 2^26
+    if (mo.frame[i] != mo.frame[0] + i || mo.out[i] - mo.out[0] != (ptrdiff_t)i * (mo.out[1] - mo.out[0]) ||
+        mo.dc[i] - mo.dc[0] != (ptrdiff_t)i * (mo.dc[1] - mo.dc[0]))
+      return false;
+  return c->slab_quads < (1u << 26) && n <= 64u;
+}
+
 static void launch_generic_mode(VxContext* c, const MultiOut& mo, float weight, dim3 grid, hipStream_t stream) {
+  if (events_possible(c, mo)) {
+    if (c->params.render_mode == VX_MODE_DEFAULT) launch_events<VX_MODE_DEFAULT>(c, mo, weight, grid, stream);
+    else launch_events<VX_MODE_NO_DDA>(c, mo, weight, grid, stream);
+    return;
+  }
   size_t lds = c->tf_len <= TF_LDS_MAX ? (size_t)c->tf_len * sizeof(float4) : 0;
   // (bounces < 1: fragment.frag:86-101 still traces the primary segment and one light sample before it tests the
   // count; render_paths loops on `n_paths < bounces` and would leave the slab unwritten -- render_generic serves it)
-  if (c->paths_variant != 0 && !c->params.debug_hits && c->params.render_mode <= VX_MODE_RAYMARCH && c->params.bounces >= 1) {
+  if (c->paths_variant == 1 && !c->params.debug_hits && c->params.render_mode <= VX_MODE_RAYMARCH && c->params.bounces >= 1) {
     switch (c->params.render_mode) {
       case VX_MODE_DEFAULT: launch_paths<VX_MODE_DEFAULT>(c, mo, weight, grid, lds, stream); break;
       case VX_MODE_NO_DDA: launch_paths<VX_MODE_NO_DDA>(c, mo, weight, grid, lds, stream); break;
@@ -522,7 +564,9 @@ int vx_create(int device_id, VxContext** out) {
   const char* v = getenv("VX_DVR_KERNEL");
   if (v && !strcmp(v, "generic")) c->dvr_variant = 0;
   const char* pk = getenv("VX_PATHS_KERNEL");
-  if (pk && !strcmp(pk, "packed")) c->paths_variant = 1;
+  if (pk && !strcmp(pk, "packed")) c->paths_variant = 1;     // path segments re-packed through LDS (vx_paths.hpp)
+  if (pk && !strcmp(pk, "generic")) c->paths_variant = 2;    // one pixel per lane for the whole path (render_generic): the default
+  if (pk && !strcmp(pk, "events")) c->paths_variant = 3;     // wave-persistent, event-batched (vx_events.hpp): measured slower
   const char* dpe = getenv("VX_DVR_DP");
   if (dpe) c->dp_env = atoi(dpe);
   const char* o = getenv("VX_DVR_ORDER");
@@ -555,11 +599,11 @@ void vx_destroy(VxContext* c) {
   if (c->order) (void)hipFree(c->order);
   for (auto& p : c->pipes) {
     if (p.stream) { (void)hipStreamSynchronize(p.stream); (void)hipStreamDestroy(p.stream); }
-    if (p.result) (void)hipFree(p.result);
-    if (p.dc) (void)hipFree(p.dc);
     if (p.done) (void)hipEventDestroy(p.done);
     if (p.merged) (void)hipEventDestroy(p.merged);
   }
+  if (c->pipe_result_pool) (void)hipFree(c->pipe_result_pool);
+  if (c->pipe_dc_pool) (void)hipFree(c->pipe_dc_pool);
   if (c->aux_stream) (void)hipStreamDestroy(c->aux_stream);
   if (c->own_stream) (void)hipStreamDestroy(c->own_stream);
   delete c;
@@ -1163,22 +1207,27 @@ static int ensure_pipes(VxContext* c, int n) {
   }
   for (auto& p : c->pipes) {
     if (p.stream) (void)hipStreamSynchronize(p.stream);
-    if (p.result) (void)hipFree(p.result);
-    if (p.dc) (void)hipFree(p.dc);
     p.result = nullptr;
     p.dc = nullptr;
   }
+  if (c->pipe_result_pool) (void)hipFree(c->pipe_result_pool);
+  if (c->pipe_dc_pool) (void)hipFree(c->pipe_dc_pool);
+  c->pipe_result_pool = nullptr;
+  c->pipe_dc_pool = nullptr;
   if ((int)c->pipes.size() < n) c->pipes.resize(n);
-  for (size_t i = 0; i < c->pipes.size(); ++i) {
+  const size_t ns = c->pipes.size();
+  VX_HIP(c, hipMalloc(&c->pipe_result_pool, ns * c->slab_quads * sizeof(float4)));
+  VX_HIP(c, hipMalloc(&c->pipe_dc_pool, ns * waves * sizeof(DevCounters)));
+  VX_HIP(c, hipMemsetAsync(c->pipe_dc_pool, 0, ns * waves * sizeof(DevCounters), c->stream));   // ordered with the launches
+  for (size_t i = 0; i < ns; ++i) {
     auto& p = c->pipes[i];
     // streams only for the rolling-window path (<= 8 slots); the multi-frame kernel needs none
     if (i < 8 && !p.stream) VX_HIP(c, hipStreamCreateWithFlags(&p.stream, hipStreamNonBlocking));
     if (!p.done) VX_HIP(c, hipEventCreateWithFlags(&p.done, hipEventDisableTiming));
     if (!p.merged) VX_HIP(c, hipEventCreateWithFlags(&p.merged, hipEventDisableTiming));
     p.has_merged = false;
-    VX_HIP(c, hipMalloc(&p.result, c->slab_quads * sizeof(float4)));
-    VX_HIP(c, hipMalloc(&p.dc, waves * sizeof(DevCounters)));
-    VX_HIP(c, hipMemsetAsync(p.dc, 0, waves * sizeof(DevCounters), c->stream));   // ordered with the launches
+    p.result = c->pipe_result_pool + i * c->slab_quads;
+    p.dc = c->pipe_dc_pool + i * waves;
   }
   VX_HIP(c, hipStreamSynchronize(c->stream));   // the fills are done before any stream launches into the new slots
   c->pipe_quads = c->slab_quads;
@@ -1466,6 +1515,7 @@ int vx_get_counters(VxContext* c, VxCounters* out) {
   out->min_launch_frames = c->min_launch_frames;
   out->max_launch_frames = c->max_launch_frames;
   out->tf_samples = c->base.tf_samples;
+  out->active_lane_slots = c->base.active_lane_slots;
   return VX_OK;
 }
 

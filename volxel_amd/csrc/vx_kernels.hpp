@@ -68,23 +68,25 @@ struct DevCounters {
   uint32_t gathers;     // 16-byte-per-lane gather wave instructions issued (tuned DVR kernels)
   uint32_t lds_reads;   // LDS tap-read wave instructions (LDS-tile kernels)
   uint32_t tf;          // samples inside the sample range (LUT fetched)
+  uint32_t active;      // lane slots that did work (event-batched path kernels)
+  uint32_t pad;
 };
 
-__global__ void zero_totals(unsigned long long* sums) { sums[threadIdx.x] = 0ull; }   // 9 totals (fold_records)
+__global__ void zero_totals(unsigned long long* sums) { sums[threadIdx.x] = 0ull; }   // 10 totals (fold_records)
 
 // sums the per-wave records of one launch slot into eight 64-bit totals and zeroes them (vx_get_counters /
 // vx_reset_counters: 64 bytes cross PCIe instead of every record)
 __global__ __launch_bounds__(256) void fold_records(DevCounters* __restrict__ recs, size_t n,
                                                     unsigned long long* __restrict__ sums) {
-  unsigned long long s[9] = {0ull, 0ull, 0ull, 0ull, 0ull, 0ull, 0ull, 0ull, 0ull};
+  unsigned long long s[10] = {0ull, 0ull, 0ull, 0ull, 0ull, 0ull, 0ull, 0ull, 0ull, 0ull};
   for (size_t i = (size_t)blockIdx.x * 256u + threadIdx.x; i < n; i += (size_t)gridDim.x * 256u) {
     const DevCounters r = recs[i];
     s[0] += r.samples; s[1] += r.slots; s[2] += r.rays; s[3] += r.pixels;
-    s[4] += r.skips; s[5] += r.grads; s[6] += r.gathers; s[7] += r.lds_reads; s[8] += r.tf;
+    s[4] += r.skips; s[5] += r.grads; s[6] += r.gathers; s[7] += r.lds_reads; s[8] += r.tf; s[9] += r.active;
     recs[i] = DevCounters{};
   }
 #pragma unroll
-  for (int k = 0; k < 9; ++k) {
+  for (int k = 0; k < 10; ++k) {
     unsigned long long x = s[k];
     for (int off = 32; off > 0; off >>= 1) x += __shfl_xor(x, off);
     if ((threadIdx.x & 63u) == 0u && x != 0ull) atomicAdd(&sums[k], x);
@@ -94,7 +96,7 @@ __global__ __launch_bounds__(256) void fold_records(DevCounters* __restrict__ re
 // `block` = logical block id (identical to blockIdx.x unless the launch is permuted by `order`)
 VXD void add_counts(DevCounters* dc, uint32_t samples, uint32_t rays, uint32_t pixels, uint32_t skips,
                     uint32_t grads, uint32_t slots, uint32_t block = 0xffffffffu, uint32_t gathers = 0u,
-                    uint32_t lds_reads = 0u, uint32_t tf = 0u) {
+                    uint32_t lds_reads = 0u, uint32_t tf = 0u, uint32_t active = 0u) {
   if ((threadIdx.x & 63u) == 0) {
     if (block == 0xffffffffu) block = blockIdx.x;
     DevCounters* w = dc + (block * (blockDim.x >> 6) + (threadIdx.x >> 6));
@@ -103,6 +105,7 @@ VXD void add_counts(DevCounters* dc, uint32_t samples, uint32_t rays, uint32_t p
     c.gathers += gathers;
     c.lds_reads += lds_reads;
     c.tf += tf;
+    c.active += active;
     c.samples += samples;
     c.slots += slots;
     c.rays += rays;

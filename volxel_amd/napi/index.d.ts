@@ -62,7 +62,7 @@ export declare class Volxel3DDicomRenderer {
   finish(): void;
   readAccum(): Float32Array;
   readDisplay(): Uint8Array;
-  counters(): { samples: number; rays: number; pixels: number; skipSteps: number; gradSamples: number; tfSamples: number; laneSlots: number; launches: number; frames: number;
+  counters(): { samples: number; rays: number; pixels: number; skipSteps: number; gradSamples: number; tfSamples: number; activeLaneSlots: number; laneSlots: number; launches: number; frames: number;
                 kernelMs: number; lastKernelMs: number; gathers: number; ldsReads: number; mergeMs: number; minLaunchFrames: number; maxLaunchFrames: number };
   resetCounters(): void;
   dispose(): void;

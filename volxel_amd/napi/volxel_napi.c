@@ -415,7 +415,7 @@ static napi_value n_get_counters(napi_env env, napi_callback_info info) {
   NAPI_OK(napi_create_double(env, (double)(val), &v));      \
   NAPI_OK(napi_set_named_property(env, o, name, v));
   PUT("samples", k.samples) PUT("rays", k.rays) PUT("pixels", k.pixels) PUT("skipSteps", k.skip_steps)
-  PUT("gradSamples", k.grad_samples) PUT("tfSamples", k.tf_samples) PUT("laneSlots", k.lane_slots) PUT("launches", k.launches) PUT("frames", k.frames)
+  PUT("gradSamples", k.grad_samples) PUT("tfSamples", k.tf_samples) PUT("activeLaneSlots", k.active_lane_slots) PUT("laneSlots", k.lane_slots) PUT("launches", k.launches) PUT("frames", k.frames)
   PUT("kernelMs", k.kernel_ms) PUT("lastKernelMs", k.last_kernel_ms) PUT("gathers", k.gathers)
   PUT("ldsReads", k.lds_reads) PUT("mergeMs", k.merge_ms) PUT("minLaunchFrames", k.min_launch_frames)
   PUT("maxLaunchFrames", k.max_launch_frames)
