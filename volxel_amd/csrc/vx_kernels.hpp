@@ -162,10 +162,13 @@ VXD void multi_slot(uint32_t p, uint32_t count, uint32_t& fslot, uint32_t& bslot
 #ifndef VX_W_DEFAULT
 #define VX_W_DEFAULT 8
 #define VX_W_NO_DDA 8
-#define VX_W_RAYMARCH 8
+// raymarch (91 % useful lanes, bound by its instruction count) is no longer forced: at 5 waves it needs no scratch and
+// runs 0.699 ms per frame against 0.704 / 0.721 / 0.732 at 6 / 7 / 8 (round 3, after the division-free reservoir)
+#define VX_W_RAYMARCH 5
 // dvr_phong has its tuned kernel (vx_dvr_lds.hpp); the generic form only serves the reference / cellquad layouts.
-// Forced to 8 waves it spilled 49-57 registers and the REFERENCE-layout build then produced wrong pixels
-// (tests/test_gpu_parity.py::test_golden_deterministic[noise32_phong-0]: 6e-2 off, fine at 4): not forced.
+// Round 2 saw wrong pixels from the REFERENCE-layout build at 8 waves: spill code placed ahead of an exec restore
+// (DESIGN.md section 5.3).  The taps are straight-line code now and every build is linted for that placement
+// (tools/check_exec_prologue.py, run by the Makefile): 8 waves again.
 #define VX_W_PHONG 8
 #endif
 constexpr int generic_min_waves(int mode) {
