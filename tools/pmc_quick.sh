@@ -8,7 +8,7 @@ cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
 OUT=gpurun_out/prof/$TAG
 mkdir -p "$OUT"
 echo "bench.py $*" > "$OUT/command.txt"
-LEAN="--no-cpu-baseline --no-skip-variant --no-mode-variants --no-side-measurements"
+LEAN="--no-cpu-baseline --no-skip-variant --no-mode-variants --no-side-measurements --no-cold"
 ARGS="$*"
 timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/kt" -- python3 bench.py $ARGS $LEAN > "$OUT/bench_kt.json" 2> "$OUT/bench_kt.err" || { tail -5 "$OUT/bench_kt.err"; exit 1; }
 pass() {
