@@ -306,7 +306,10 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(PHONG ? (SK
       const int gy = oy + (int)yy, gz = oz + (int)zz;
       const bool rin = row < (uint32_t)TL::ROWS && (uint32_t)gy < ey && (uint32_t)gz < ez;
       // 16-byte units from the start of the layout to the brick row (y,z) of brick column 0
-      const uint32_t rowbase = ((((uint32_t)gz >> 3) * bcy + ((uint32_t)gy >> 3)) * bcx << 7) +
+      // (24-bit multiplies: brick coordinates are below 2^10, their products below 2^24 for every volume the layout
+      // can index; hipcc otherwise picks the quarter-rate v_mad_u64_u32 / v_mul_lo_u32.  Rows outside the volume are
+      // selected away, whatever their index came to.)
+      const uint32_t rowbase = (mad24(mad24((uint32_t)gz >> 3, bcy, (uint32_t)gy >> 3) & 0xffffffu, bcx, 0u) << 7) +
                                ((((uint32_t)gz & 7u) << 4) | (((uint32_t)gy & 7u) << 1));
 #pragma unroll
       for (int c = 0; c < NC; ++c) {
