@@ -252,8 +252,12 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(PHONG ? (SK
     const float lo = (float)lo_cell, hi = lo + (float)n_cells;
     const bool bw = dqa < 0.0f;
     const float face = bw ? lo : hi;
-    float c = ceilf((face - q0a) * iva);
-    c = fminf(c, 16777216.0f);                       // also turns a NaN estimate into "far away"
+    // never beyond the ray's own last sample: q(n - 1) inside means every remaining sample is (monotone), and the
+    // estimate of a ray that barely moves along this axis (|dq| -> 0: c in the millions or infinite) stays a sample
+    // index the test below can evaluate -- clamped at 2^24 such a ray failed the test and crawled one step per
+    // window (found as a 0.6 ms single-frame launch: two such lanes per frame hold their waves for milliseconds).
+    // fminf also turns a NaN estimate into n.
+    float c = fminf(ceilf((face - q0a) * iva), nray);
     const float q1 = fma_(c - 1.0f, dqa, q0a);
     const bool in1 = (q1 < face) != bw;              // forward: q1 < hi; backward: q1 >= lo
     return in1 ? c : -1.0f;
