@@ -9,10 +9,11 @@
 //
 // MEASURED OUTCOME (config 3, 1080p, 32 frames per launch, bounces 1): lane utilisation of the
 // march 0.36 -> 0.63 (default) and 0.43 -> 0.72 (no_dda), bit-identical images and counts -- and 0.66 / 1.28 ms per
-// frame against render_generic's 0.46 / 0.72.  The modes are not bound by vector-ALU issue: every sample is a pair of
-// 16-byte gathers at a random free-flight position (two cache-line look-ups per lane, no two lanes on one line) at
-// the end of a dependent chain rng -> log -> position -> gather -> classify.  What they need is waves in flight, and
-// this kernel pays for its dense lanes with 80 registers (6 waves per SIMD instead of 8), spills and LDS traffic.
+// frame against render_generic's 0.46 / 0.72.  rocprofv3 (tools/events_pmc.sh): the event passes, the unified step's
+// branches and the LDS-resident path state cost as many vector instructions as the denser march saves (6.46 -> 6.81 G
+// and 8.86 -> 9.68 G per 16-frame launch), and the issue rate falls (0.68 -> 0.54, 0.58 -> 0.38 of the clocks): every
+// step ends in a dependent chain rng -> log -> position -> gather -> classify that only waves in flight hide, and this
+// kernel needs 80 registers (6 waves per SIMD instead of 8), spills and LDS traffic for its dense lanes.
 // It therefore ships as the opt-in form (VX_PATHS_KERNEL=events), tested for bit-identity; render_generic stays the
 // default for these modes.
 //
