@@ -197,3 +197,29 @@ def test_hip_single_scatter_expectation(oracle, mode):
     ratio = mean[interior].sum() / want[interior].sum()
     assert abs(ratio - 1.0) <= 0.01 + BIAS[mode], ratio
     r.close()
+
+
+def test_trilinear_reproduces_a_linear_field(oracle):
+    """A5 pins its own conventions on a linear ramp: trilinear interpolation is exact on linear functions, so with voxel
+    centres at integer + 1/2 (common.glsl:61-69: fract / floor of p - 1/2) the look-up at a continuous index position p
+    must return ramp(p - 1/2) up to the brick quantisation (half a code of the brick's range, range ends in binary16).
+    A half-voxel shift, swapped axes or a wrong tap order would be off by tens of codes."""
+    L = oracle.lib()
+    n = 40
+    z, y, x = np.meshgrid(np.arange(n), np.arange(n), np.arange(n), indexing="ij")
+    ramp = lambda X, Y, Z: 200.0 + 30.0 * X + 20.0 * Y + 10.0 * Z
+    vox = ramp(x, y, z).astype(np.uint16)
+    vmax = float(vox.max())
+    g = oracle.BrickGrid(vox, (1.0, 1.0, 1.0))
+    vol = oracle.make_volume(g)
+    rng = np.random.default_rng(3)
+    worst = 0.0
+    for p in rng.uniform(9.0, 31.0, size=(400, 3)):      # bricks 1..3: their dilated windows see data only (quirk Q4)
+        got = L.vxo_lookup_density_trilinear(vol, 1.0, float(p[0]), float(p[1]), float(p[2]))
+        want = ramp(p[0] - 0.5, p[1] - 0.5, p[2] - 0.5) / vmax
+        worst = max(worst, abs(got - want))
+    # a brick's range here spans <= (12 * 30 + 12 * 20 + 12 * 10) / vmax (the dilated 12^3 window, brick.rs:101-103):
+    # half a u8 code of it + binary16 rounding of the range ends (2^-11 relative)
+    brick_range = 12.0 * 60.0 / vmax
+    assert worst <= 0.5 * brick_range / 255.0 + 2.0 ** -11 + 1e-6, worst
+    assert worst < 0.25 * 10.0 / vmax * 2.5          # far below what a half-voxel shift along the slowest axis would give (5 / vmax)
