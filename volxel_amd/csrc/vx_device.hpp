@@ -273,7 +273,11 @@ VXD float lookup_density_nearest(const DevVolume& v, int x, int y, int z) {
 }
 
 // the eight taps of cell (ix,iy,iz) mixed x -> y -> z with the fractions given (common.glsl:62-68)
-template <int LAYOUT>
+// IN_LATTICE (cellquad only): the caller guarantees a cell inside the apron lattice [-1, extent + 6] -- true for every
+// sample position inside the (clipped) volume box, where the path-traced modes take all their samples: floor(p - 1/2)
+// of p in [0, extent] is in [-1, extent - 1].  The clamp stays (a stray or NaN position reads defined memory), the
+// eight selects that zero an out-of-lattice cell go.
+template <int LAYOUT, bool IN_LATTICE = false>
 VXD float trilinear_cell(const DevVolume& v, float density_scale, int ix, int iy, int iz, float fx, float fy, float fz) {
   float v000, v100, v010, v110, v001, v101, v011, v111;
   if (LAYOUT == LAYOUT_CQ) {
@@ -282,7 +286,7 @@ VXD float trilinear_cell(const DevVolume& v, float density_scale, int ix, int iy
     // a cell outside the apron lattice [-1, extent + 6] has eight zero taps: the index is clamped into the lattice
     // and the quads selected to 0 (straight-line; mix of zeros = +0, times the scale as before)
     const int mxx = (int)v.extent[0] + 7, mxy = (int)v.extent[1] + 7, mxz = (int)v.extent[2] + 7;
-    const bool in = (uint32_t)(ix + 1) <= (uint32_t)mxx && (uint32_t)(iy + 1) <= (uint32_t)mxy && (uint32_t)(iz + 1) <= (uint32_t)mxz;
+    const bool in = IN_LATTICE || ((uint32_t)(ix + 1) <= (uint32_t)mxx && (uint32_t)(iy + 1) <= (uint32_t)mxy && (uint32_t)(iz + 1) <= (uint32_t)mxz);
     const uint32_t cx = (uint32_t)clamp0_i32(ix + 1, mxx), cy = (uint32_t)clamp0_i32(iy + 1, mxy), cz = (uint32_t)clamp0_i32(iz + 1, mxz);
     const uint32_t b = ((cz >> 3) * v.cq_bc[1] + (cy >> 3)) * v.cq_bc[0] + (cx >> 3);
     const size_t o = (size_t)b * CQ_BRICK_QUADS + cq_cell(cx & 7u, cy & 7u, cz & 7u);
@@ -317,12 +321,12 @@ VXD float trilinear_cell(const DevVolume& v, float density_scale, int ix, int iy
 }
 
 // A5: lookup_density_trilinear, common.glsl:61-69
-template <int LAYOUT>
+template <int LAYOUT, bool IN_LATTICE = false>
 VXD float lookup_density_trilinear(const DevVolume& v, float density_scale, V3 p) {
   float qx = p.x - 0.5f, qy = p.y - 0.5f, qz = p.z - 0.5f;
   float flx = floorf(qx), fly = floorf(qy), flz = floorf(qz);
   float fx = qx - flx, fy = qy - fly, fz = qz - flz;
-  return trilinear_cell<LAYOUT>(v, density_scale, f2i(flx), f2i(fly), f2i(flz), fx, fy, fz);
+  return trilinear_cell<LAYOUT, IN_LATTICE>(v, density_scale, f2i(flx), f2i(fly), f2i(flz), fx, fy, fz);
 }
 
 // lookup_majorant, common.glsl:50-53: the range-texture texel (level `mip`, .x = R = max) by cell, 0 outside the level

@@ -21,8 +21,10 @@ struct Frame {
     if (!(d < p.sample_range[0] || d > p.sample_range[1])) c.tf++;
     return lookup_transfer(tf, p.sample_range[0], p.sample_range[1], d);
   }
+  // the samples of the march loops lie inside the clipped volume box (t in [near, far) of the slab test), hence inside
+  // the apron lattice of the cellquad layout
   VXD float trilinear(V3 ip) const {
-    return lookup_density_trilinear<LAYOUT>(v, p.volume_density_scale, ip);
+    return lookup_density_trilinear<LAYOUT, true>(v, p.volume_density_scale, ip);
   }
   // lookup_density_stochastic, common.glsl:56-58,72-76
   VXD float density_stochastic(V3 ipos, Rng& s) const {
