@@ -96,6 +96,17 @@ VXD int f2i(float x) {
   return r;
 }
 
+// -log(1 - r) for a draw r in [0, 1): the argument 1 - r lies in [2^-24, 1], never denormal, zero, infinite or NaN, so
+// logf's scaling of denormal arguments and its pass-through of infinities (seven instructions, 26 clocks at gfx950's
+// rates -- tools/op_rate.hip -- per free flight) select nothing.  What is left is logf's own sequence, the hardware log2
+// times ln 2 as a two-float product: the same bits for every argument in range.
+VXD float neg_log_one_minus(float r) {
+  const float y = __builtin_amdgcn_logf(1.0f - r);
+  const float hi = y * 0x1.62e42ep-1f;                                             // 0x3f317217
+  const float lo = __builtin_fmaf(y, 0x1.efa39ep-25f, __builtin_fmaf(y, 0x1.62e42ep-1f, -hi));   // 0x3377d1cf
+  return -(hi + lo);
+}
+
 // lane mask of a per-lane condition (HIP's __ballot takes an int: the bool is first materialised as 0 / 1 and compared
 // again, two vector instructions per use)
 VXD unsigned long long ballot(bool b) { return __builtin_amdgcn_ballot_w64(b); }
@@ -348,9 +359,9 @@ struct TfView {
 typedef const float4 __attribute__((address_space(3))) * LdsFloat4Ptr;
 VXD float4 lookup_transfer(const TfView& tf, const float sr0, const float sr1, float d) {
   if (d < sr0 || d > sr1) return make_float4(0.f, 0.f, 0.f, 0.f);
-  int i = f2i(floorf(d * tf.lenf));
-  i = i < 0 ? 0 : i;
-  i = i > (int)tf.len - 1 ? (int)tf.len - 1 : i;
+  // floor(d * L) clamped to [0, L - 1]: the conversion truncates toward zero, which is floor for the products >= 0 and
+  // lands on entry 0 like floor does for the negative ones
+  const int i = clamp0_i32(f2i(d * tf.lenf), (int)tf.len - 1);
   if (tf.in_lds) {
     const LdsFloat4Ptr e = (LdsFloat4Ptr)tf.lut + i;
     return make_float4(e->x, e->y, e->z, e->w);
@@ -360,8 +371,7 @@ VXD float4 lookup_transfer(const TfView& tf, const float sr0, const float sr1, f
 
 // A7 for a march that only needs the extinction (raymarch.glsl:20-21,41-43 read .a; .rgb only at the collision)
 VXD float lookup_transfer_alpha(const TfView& tf, const float sr0, const float sr1, float d) {
-  int i = f2i(floorf(d * tf.lenf));
-  i = clamp0_i32(i, (int)tf.len - 1);
+  const int i = clamp0_i32(f2i(d * tf.lenf), (int)tf.len - 1);
   float a;
   if (tf.in_lds) a = ((LdsFloat4Ptr)tf.lut + i)->w;
   else a = tf.lut[i].w;

@@ -118,10 +118,10 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(VX_W_EVENTS
     if (DDA) {
       ri = v3(1.0f / idir.x, 1.0f / idir.y, 1.0f / idir.z);          // dda.glsl:24,68
       t = near + 1e-6f;
-      tau = -logf(1.0f - rng(s));
+      tau = neg_log_one_minus(rng(s));
       mip = 3.0f;
     } else {
-      t = fma_(-logf(1.0f - rng(s)), p.volume_inv_maj, near);        // normal.glsl:13,40
+      t = fma_(neg_log_one_minus(rng(s)), p.volume_inv_maj, near);        // normal.glsl:13,40
     }
     return true;
   };
@@ -198,10 +198,10 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(VX_W_EVENTS
           }
           if (status == EV_MARCH) {
             if (DDA) {
-              tau = -logf(1.0f - rng(s));                             // dda.glsl:58,94
+              tau = neg_log_one_minus(rng(s));                             // dda.glsl:58,94
               mip = gl_max(0.0f, mip - 2.0f);
             } else {
-              t = fma_(-logf(1.0f - rng(s)), p.volume_inv_maj, t);    // normal.glsl:28,54
+              t = fma_(neg_log_one_minus(rng(s)), p.volume_inv_maj, t);    // normal.glsl:28,54
             }
           }
         }

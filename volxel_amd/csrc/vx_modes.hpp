@@ -61,7 +61,7 @@ struct Frame {
     if (!slab(ray, near, far)) return false;
     V3 ipos, idir;
     to_index(p, ray, ipos, idir);
-    float tau_target = -logf(1.0f - rng(s));
+    float tau_target = neg_log_one_minus(rng(s));
     float dt = (far - near) / 64.0f;
     near = fma_(rng(s), dt, near);
     float tau = 0.0f, kf = 0.0f;
@@ -107,7 +107,7 @@ struct Frame {
                    bz = (uint32_t)(f2i(floorf(curr.z)) >> sh);
     const bool in = bx < v.bc[0] && by < v.bc[1] && bz < v.bc[2];
     // 24-bit multiplies: at most 128 bricks per axis (brick.rs:77-81), four levels
-    const uint32_t i = mad24(mad24(mad24((uint32_t)mip, v.bc[2], bz), v.bc[1], by), v.bc[0], bx);
+    const uint32_t i = mad24_s(mad24_s(mad24_s((uint32_t)mip, v.bc[2], bz), v.bc[1], by), v.bc[0], bx);
     return v.lmaj[in ? i : v.lmaj_cells];   // the entry after the last level holds the value outside the grid
   }
   // round(mip), half away from zero (quirk Q12): mip is a multiple of 1/4 in [0, 3], so floor(mip + 1/2) is the same
@@ -118,7 +118,7 @@ struct Frame {
     V3 ipos, idir;
     to_index(p, ray, ipos, idir);
     V3 ri = v3(1.0f / idir.x, 1.0f / idir.y, 1.0f / idir.z);
-    float t = near + 1e-6f, Tr = 1.0f, tau = -logf(1.0f - rng(s)), mip = 3.0f;
+    float t = near + 1e-6f, Tr = 1.0f, tau = neg_log_one_minus(rng(s)), mip = 3.0f;
     uint32_t step = 0;
     while (t < far && (step++ < 100u)) {
       V3 curr = madd3(ipos, t, idir);
@@ -143,7 +143,7 @@ struct Frame {
           Tr /= 1.0f - prob;
         }
       }
-      tau = -logf(1.0f - rng(s));
+      tau = neg_log_one_minus(rng(s));
       mip = gl_max(0.0f, mip - 2.0f);
     }
     return Tr;
@@ -155,7 +155,7 @@ struct Frame {
     to_index(p, ray, ipos, idir);
     V3 ri = v3(1.0f / idir.x, 1.0f / idir.y, 1.0f / idir.z);
     t = near + 1e-6f;
-    float tau = -logf(1.0f - rng(s)), mip = 3.0f;
+    float tau = neg_log_one_minus(rng(s)), mip = 3.0f;
     uint32_t guard = 0;  // the reference loop is unbounded; a wedged wave would hang the GPU
     while (t < far && guard++ < LOOP_GUARD) {
       V3 curr = madd3(ipos, t, idir);
@@ -177,7 +177,7 @@ struct Frame {
         thr.x *= rgba.x; thr.y *= rgba.y; thr.z *= rgba.z;
         return true;
       }
-      tau = -logf(1.0f - rng(s));
+      tau = neg_log_one_minus(rng(s));
       mip = gl_max(0.0f, mip - 2.0f);
     }
     return false;
@@ -189,7 +189,7 @@ struct Frame {
     if (!slab(ray, near, far)) return 1.0f;
     V3 ipos, idir;
     to_index(p, ray, ipos, idir);
-    float t = fma_(-logf(1.0f - rng(s)), p.volume_inv_maj, near), Tr = 1.0f;
+    float t = fma_(neg_log_one_minus(rng(s)), p.volume_inv_maj, near), Tr = 1.0f;
     uint32_t guard = 0;
     while (t < far && guard++ < LOOP_GUARD) {
       float4 rgba = transfer(trilinear(madd3(ipos, t, idir)) * p.volume_inv_maj);
@@ -201,7 +201,7 @@ struct Frame {
         if (rng(s) < prob) return 0.0f;
         Tr /= 1.0f - prob;
       }
-      t = fma_(-logf(1.0f - rng(s)), p.volume_inv_maj, t);
+      t = fma_(neg_log_one_minus(rng(s)), p.volume_inv_maj, t);
     }
     return Tr;
   }
@@ -210,7 +210,7 @@ struct Frame {
     if (!slab(ray, near, far)) return false;
     V3 ipos, idir;
     to_index(p, ray, ipos, idir);
-    t = fma_(-logf(1.0f - rng(s)), p.volume_inv_maj, near);
+    t = fma_(neg_log_one_minus(rng(s)), p.volume_inv_maj, near);
     uint32_t guard = 0;
     while (t < far && guard++ < LOOP_GUARD) {
       float4 rgba = transfer(trilinear(madd3(ipos, t, idir)) * p.volume_inv_maj);
@@ -223,7 +223,7 @@ struct Frame {
         thr.z *= rgba.z * p.volume_albedo[2];
         return true;
       }
-      t = fma_(-logf(1.0f - rng(s)), p.volume_inv_maj, t);
+      t = fma_(neg_log_one_minus(rng(s)), p.volume_inv_maj, t);
     }
     return false;
   }
