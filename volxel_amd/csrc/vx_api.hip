@@ -1071,7 +1071,10 @@ int vx_resize(VxContext* c, uint32_t w, uint32_t h) {
 }
 
 static bool tuned_possible(const VxContext* c) {
-  return c->dvr_variant != 0 && !c->params.debug_hits && c->tf_len <= TF_LDS_MAX;
+  // (an early-termination threshold <= 0 -- an epsilon >= 1: every ray ends at its first contributing sample -- is
+  // served by render_generic, whose Frame::dvr spells the test as the oracle does; the tuned kernels assume tau >= ert
+  // implies a contributing sample)
+  return c->dvr_variant != 0 && !c->params.debug_hits && c->tf_len <= TF_LDS_MAX && c->params.dvr_ert_tau > 0.0f;
 }
 // the LDS-window kernel (vx_dvr_lds.hpp): DVR on the brickf32 layout, Phong wherever brickf32 data is resident
 static bool use_lds_kernel(const VxContext* c) {

@@ -168,7 +168,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(PHONG ? (SK
   const float sr0 = p.sample_range[0], sr1 = p.sample_range[1];
   const float lenf = (float)tf_len;
   const int last = (int)tf_len - 1;
-  const float ert = p.dvr_ert_tau;
+  const float ert = p.dvr_ert_tau;   // > 0: use_lds_kernel (vx_api.hip)
   const uint32_t ex = v.extent[0], ey = v.extent[1], ez = v.extent[2];
   const uint32_t bcx = v.bc[0], bcy = v.bc[1];
   const float4* __restrict__ bf4 = reinterpret_cast<const float4*>(v.bf);   // 16-byte units: 64 GiB of layout in 32 bits
@@ -441,6 +441,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(PHONG ? (SK
     int s = 0;
     bool more;
     bool go = kf < klim;     // carried: the bottom test of one trip is the lane mask of the next
+    unsigned long long gom = ballot(go);   // the same as a scalar (the ballot of a carried bool would be materialised)
 #pragma unroll 1
     do {
       n_slots += 64u;
@@ -477,8 +478,9 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(PHONG ? (SK
       // A7 / A12 only where they can matter: a sample outside the sample range, or whose TF entry has alpha 0, leaves
       // tau, T and C exactly as they are, and on this kind of data most wave steps have no lane inside the range at
       // all (config 3: 82 %), so the LUT fetch, the classification and the composite sit behind one wave-uniform branch
-      const bool in_range = eval & !(dn < sr0 || dn > sr1);
-      const unsigned long long rm = ballot(in_range);
+      // (the lane mask as the AND of three compare results: the ballot of a conjunction is materialised with a select
+      // and a second compare, two half-rate vector instructions per step -- profiles/r03_op_rates.txt)
+      const unsigned long long rm = (TEST ? ballot(eval) : gom) & ballot(!(dn < sr0)) & ballot(!(dn > sr1));
       if (rm != 0ull) {
         n_tf += (uint32_t)__builtin_popcountll(rm);
 #ifdef VX_COUNT_INRANGE   // diagnostic build: skip_steps counts the wave steps that enter this block
@@ -486,7 +488,10 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(PHONG ? (SK
 #endif
         const int ti = clamp0_i32((int)(dn * lenf), last);   // dn >= 0: truncation == floor
         float4 rgba = tf_lds[ti];
-        const float alpha = in_range ? rgba.w : 0.0f;
+        // alpha of the lanes in `rm`, 0 elsewhere: the select takes the scalar mask as it stands (spelled on the bool, the
+        // compiler evaluates both range compares a second time)
+        float alpha;
+        asm("v_cndmask_b32_e64 %0, 0, %1, %2" : "=v"(alpha) : "v"(rgba.w), "s"(rm));
         const bool contrib = alpha > 0.0f;
         if (PHONG) {
           const unsigned long long cm = ballot(contrib);
@@ -534,24 +539,27 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(PHONG ? (SK
         Cy = fma_(dT, rgba.y, Cy);
         Cz = fma_(dT, rgba.z, Cz);
         T = Tn;
-        // early ray termination (contrib && tau >= ert): the ray has no further samples (nray = -1, klim = 0); its T
+        // early ray termination (vx_oracle.c dvr_pixel: contrib && tau >= ert): the ray has no further samples; its T
         // stays exp2(-tau log2 e), so that nothing later in the march touches its C, and becomes 0 after the march
-        const bool done = contrib && (tau >= ert);
-        nray = done ? -1.0f : nray;
-        klim = done ? 0.0f : klim;
+        // ert > 0 (the launcher sends an epsilon >= 1 to render_generic): only a contributing sample can carry tau over
+        // it, and the ray ends right there, so `tau >= ert` alone says "terminated" for every lane, now and later -- no
+        // compare on alpha here, and nray follows once per window, after the march
+        klim = tau >= ert ? 0.0f : klim;
       }
       // the lanes that stepped move on to their next sample (the others recompute the position they already hold)
       kf = go ? kf + 1.0f + jump : kf;
       next_sample();
       ++s;
       go = kf < klim;
-      more = (s < S) & (ballot(go) != 0ull);   // somebody can still step in this window
+      gom = ballot(go);
+      more = (s < S) & (gom != 0ull);   // somebody can still step in this window
     } while (more);
   };
   while (true) {
     if (ballot(is_alive()) == 0ull) break;
     if (SKIP && wtest) march(std::integral_constant<bool, SKIP>{});
     else march(std::false_type{});
+    nray = tau >= ert ? -1.0f : nray;   // the rays the march terminated
     // ---- next window ------------------------------------------------------------------------------------------------
     const unsigned long long live = ballot(is_alive());
     if (live == 0ull) break;
