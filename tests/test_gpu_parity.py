@@ -700,6 +700,8 @@ EDGE_CASES = {
     "step_tiny": ((24, 16), dict(dvr_step_voxels=0.03125), None),
     "ert_off": ((40, 32), dict(dvr_ert_epsilon=1e-30), None),
     "ert_immediate": ((40, 32), dict(dvr_ert_epsilon=0.9999), None),
+    "ert_epsilon_one": ((40, 32), dict(dvr_ert_epsilon=1.0), None),    # threshold tau 0: every ray ends at its first
+    "ert_epsilon_two": ((40, 32), dict(dvr_ert_epsilon=2.0), None),    # contributing sample (served by render_generic)
     "dense": ((40, 32), dict(density_multiplier=50.0), None),
     "tf_len_1": ((40, 32), dict(), 1),
     "tf_len_2": ((40, 32), dict(), 2),

@@ -245,7 +245,10 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(PHONG ? (SK
   // allows; a step too low only ends the lane's run in this window one sample early.  Either way the lane never reads
   // outside the tile and the window sequence only affects speed, never which samples are evaluated.
   float klim = 0.0f;
-  int tile_base = 0;   // LDS byte address of cell (0,0,0) of the index grid in the resident tile (wave uniform)
+  // LDS byte address of cell (0,0,0) of the index grid in the resident tile (wave uniform), as a float in a VECTOR
+  // register: the address of a sample's cell is three full-rate fmas on it and one conversion (an fma with a scalar
+  // source issues at half rate, profiles/r03_op_rates.txt)
+  float tile_base = 0.0f;
   const int tile_addr = (int)(uint32_t)(uintptr_t)(LdsFloatPtr)tile;   // LDS byte address of the wave's tile
   auto axis_limit = [&](float q0a, float dqa, float iva, int lo_cell, int n_cells) {
     // cells [lo_cell, lo_cell + n_cells) are steppable: lo <= q < hi
@@ -271,7 +274,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(PHONG ? (SK
     k = fmaxf(k, kf + 1.0f);                         // the current sample is inside (integer test): one step at least
     k = fminf(k, nray);
     klim = now ? k : 0.0f;
-    tile_base = tile_addr - 4 * ((LOz * SS) + (LOy * RS) + LOx);
+    tile_base = (float)(tile_addr - 4 * ((LOz * SS) + (LOy * RS) + LOx));   // |.| < 2^23: exact
+    asm volatile("" : "+v"(tile_base));
   };
   // exact window for the lanes as they stand; lanes too far apart for one window (a wave astride two entry faces of
   // the clip box): serve the first live lane
@@ -457,11 +461,11 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(PHONG ? (SK
       }
       // (without skipping a lane evaluates one sample per step it takes: its count is kf after the march)
       if (SKIP) n_samples += (uint32_t)__builtin_popcountll(ballot(eval));
-      // byte address of the sample's cell in the tile: (z * SS + y * RS + x) * 4 + tile_base, the products exact in
-      // fp32 (cells are integers below 2^13, the strides below 2^9).  A lane that does not step (its pending sample
+      // byte address of the sample's cell in the tile: (z * SS + y * RS + x) * 4 + tile_base, every partial sum an
+      // integer below 2^23, exact in fp32 (cells are below 2^13, the byte strides below 2^11).  A lane that does not step (its pending sample
       // lies outside this window) reads the tile's first cell instead: every read stays inside the wave's tile.
-      const int cell = (int)fma_(flz, (float)SS, fma_(fly, (float)RS, flx));
-      const int addr = go ? (cell << 2) + tile_base : tile_addr;
+      const int cell_addr = (int)fma_(flz, (float)(4 * SS), fma_(fly, (float)(4 * RS), fma_(flx, 4.0f, tile_base)));
+      const int addr = go ? cell_addr : tile_addr;
       const LdsFloatPtr tp = (LdsFloatPtr)(uintptr_t)(uint32_t)addr;
       const LdsFloatPtr tq = tp + SS;             // slice z + 1
       const float v000 = tp[0], v100 = tp[1], v010 = tp[RS], v110 = tp[RS + 1];
@@ -480,8 +484,11 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(PHONG ? (SK
       // all (config 3: 82 %), so the LUT fetch, the classification and the composite sit behind one wave-uniform branch
       // (the lane mask as the AND of three compare results: the ballot of a conjunction is materialised with a select
       // and a second compare, two half-rate vector instructions per step -- profiles/r03_op_rates.txt)
-      const unsigned long long rm = (TEST ? ballot(eval) : gom) & ballot(!(dn < sr0)) & ballot(!(dn > sr1));
-      if (rm != 0ull) {
+      // (the upper bound is only tested where the lower one holds for some lane: on this kind of data the lower bound
+      // alone turns 80 % of the wave steps away)
+      const unsigned long long rlo = (TEST ? ballot(eval) : gom) & ballot(!(dn < sr0));
+      if (rlo != 0ull) {
+        const unsigned long long rm = rlo & ballot(!(dn > sr1));
         n_tf += (uint32_t)__builtin_popcountll(rm);
 #ifdef VX_COUNT_INRANGE   // diagnostic build: skip_steps counts the wave steps that enter this block
         if (!SKIP) n_skipped += 1u;
