@@ -192,9 +192,9 @@ struct Frame {
     float t = fma_(neg_log_one_minus(rng(s)), p.volume_inv_maj, near), Tr = 1.0f;
     uint32_t guard = 0;
     while (t < far && guard++ < LOOP_GUARD) {
-      float4 rgba = transfer(trilinear(madd3(ipos, t, idir)) * p.volume_inv_maj);
+      const float a = transfer_alpha(trilinear(madd3(ipos, t, idir)) * p.volume_inv_maj);
       c.samples++;
-      float d = p.volume_maj * rgba.w;
+      float d = p.volume_maj * a;
       Tr *= fma_(-d, p.volume_inv_maj, 1.0f);
       if (Tr < 0.1f) {
         float prob = 1.0f - Tr;
@@ -211,21 +211,36 @@ struct Frame {
     V3 ipos, idir;
     to_index(p, ray, ipos, idir);
     t = fma_(neg_log_one_minus(rng(s)), p.volume_inv_maj, near);
-    uint32_t guard = 0;
-    while (t < far && guard++ < LOOP_GUARD) {
-      float4 rgba = transfer(trilinear(madd3(ipos, t, idir)) * p.volume_inv_maj);
-      c.samples++;
-      float d = p.volume_maj * rgba.w;
-      float p_real = d * p.volume_inv_maj;
-      if (rng(s) < p_real) {
-        thr.x *= rgba.x * p.volume_albedo[0];
-        thr.y *= rgba.y * p.volume_albedo[1];
-        thr.z *= rgba.z * p.volume_albedo[2];
-        return true;
-      }
-      t = fma_(neg_log_one_minus(rng(s)), p.volume_inv_maj, t);
+    // One exit, at the bottom (the reference's loop leaves from its middle on a collision and from its top at the far
+    // face: the compiler answers two exits with a register copy per carried value and trip).  The free flight of :55 is
+    // drawn for every lane and kept by the lanes that go on, so a lane that collides leaves with the state and the t
+    // of :48-52.
+    bool hit = false;
+    float dn = 0.0f;
+    if (t < far) {
+      uint32_t guard = 0;
+      bool more;
+#pragma unroll 1
+      do {
+        dn = trilinear(madd3(ipos, t, idir)) * p.volume_inv_maj;
+        const float a = transfer_alpha(dn);
+        c.samples++;
+        const float d = p.volume_maj * a;
+        const float p_real = d * p.volume_inv_maj;
+        hit = rng(s) < p_real;
+        Rng s2 = s;
+        const float tn = fma_(neg_log_one_minus(rng(s2)), p.volume_inv_maj, t);
+        s.x = hit ? s.x : s2.x; s.y = hit ? s.y : s2.y; s.z = hit ? s.z : s2.z; s.w = hit ? s.w : s2.w;
+        t = hit ? t : tn;
+        more = !hit & (t < far) & (++guard < LOOP_GUARD);
+      } while (more);
     }
-    return false;
+    if (!hit) return false;
+    const float4 rgba = lookup_transfer(tf, p.sample_range[0], p.sample_range[1], dn);   // the colour, once
+    thr.x *= rgba.x * p.volume_albedo[0];
+    thr.y *= rgba.y * p.volume_albedo[1];
+    thr.z *= rgba.z * p.volume_albedo[2];
+    return true;
   }
 
   // sampling.glsl:11-44
