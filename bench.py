@@ -173,14 +173,22 @@ VALU_CLK_PER_INST = 2.0   # MI355X_MICROARCH.md: a wave64 VALU instruction issue
 NOMINAL_CLOCK_GHZ = 2.4   # MI355X_MICROARCH.md: max clock 2400 MHz
 N_SIMDS = 1024            # 256 CUs x 4 SIMDs
 # Vector instructions the bit-exact march cannot do without, per sample and lane (DESIGN.md section 6 derives them):
-#   position q = fma(k, dq, q0) per axis 3, floor 3, fraction 3, complement 1 - f 3, tile address 4 (two fmas on the float
-#   cells, one conversion, one shift-add), the seven lerps of common.glsl:62-68 as mul + fma 14, density scale and
+#   position q = fma(k, dq, q0) per axis 3, floor 3, fraction 3, complement 1 - f 3, tile address 4 (three fmas on the float
+#   cells, one conversion), the seven lerps of common.glsl:62-68 as mul + fma 14, density scale and
 #   inv_maj 2, sample-range test 2, step count 1                                                          = 35
 # and per sample that lies inside the sample range (fetches a transfer-function entry and is composited):
 #   LUT index 3 (mul, convert, clamp), address 1, alpha * maj 1, tau fma 1, exp2 argument 1, exp2 1, T_prev - T 1,
 #   three colour fmas 3, termination test 1                                                               = 13
 NECESSARY_VALU = {"per_sample": 35, "per_tf_sample": 13,
                   "phong_per_shaded_sample": 0}   # (the Phong gradient is not part of the headline workload)
+# The same lists priced with the issue rates tools/op_rate.hip measured on the device (profiles/r03_op_rates.txt): 2 clocks
+# per wave64 instruction for fp32 fma / mul / add / sub and u32 add, 4 for floor, conversions, compares, selects, clamps
+# and shift-adds, 8 for exp2:
+#   per sample: fmas of position and address 6 x 2, floor 3 x 4, fraction and complement 6 x 2, conversion 4, lerps 14 x 2,
+#   scales 2 x 2, range test 2 x 4, step count 2                                                          = 82 clocks
+#   per sample in range: index mul 2 + convert 4 + clamp 4, address 4, alpha * maj 2, tau fma 2, exp2 argument 2, exp2 8,
+#   T_prev - T 2, colour fmas 3 x 2, termination compare 4                                                = 40 clocks
+NECESSARY_CLK = {"per_sample": 82, "per_tf_sample": 40}
 
 
 def issue_block(r, c, entry):
@@ -452,6 +460,15 @@ def main():
                          "per sample inside the sample range, / 64 lanes; per-ray set-up, window placement and idle lanes are "
                          "NOT counted as necessary) per launch / kernel time, against 1024 SIMDs x 2.4 GHz / 2 clocks per instruction",
             "necessary_valu_per_launch": int(need), "necessary_model": NECESSARY_VALU,
+            "priced": {
+                "frac": round((c.samples * NECESSARY_CLK["per_sample"] + c.tf_samples * NECESSARY_CLK["per_tf_sample"]) / 64.0 / launches
+                              / (avg_kernel_s * N_SIMDS * NOMINAL_CLOCK_GHZ * 1e9), 4) if avg_kernel_s > 0 else None,
+                "necessary_clk_model": NECESSARY_CLK,
+                "note": "the same necessary instructions priced with the issue rates measured on this device (tools/op_rate.hip, "
+                        "profiles/r03_op_rates.txt: 2 clocks for fp32 fma / mul / add / sub and u32 add, 4 for floor, conversions, "
+                        "compares, selects and clamps, 8 for exp2) over the SIMD clocks of the launch at 2.4 GHz: the share of the "
+                        "vector ALUs' time the necessary work would take -- no instruction mix of this march can reach the "
+                        "2-clock peak `frac` is quoted against"},
             "tf_samples_per_frame": int(c.tf_samples // max(c.frames, 1)),
             "algorithmic_gbs": round(achieved, 1),
             "algorithmic_gbs_note": "SURVEY 8(d) byte model / kernel time; exceeds the 8000 GB/s HBM peak because the kernel stages "

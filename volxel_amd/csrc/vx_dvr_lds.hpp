@@ -49,6 +49,9 @@ namespace vx {
 #ifndef VX_LDS_S
 #define VX_LDS_S 16
 #endif
+#ifndef VX_LDS_S_PHONG   // steps per window of the shading kernel (12 / 16 / 20 / 24: 0.365 / 0.370 / 0.375 / 0.377 ms per frame)
+#define VX_LDS_S_PHONG 12
+#endif
 template <bool PHONG>
 struct LdsTile {
   static constexpr int X = VX_LDS_X;             // X / 4 chunks of 16 bytes per row
@@ -590,9 +593,9 @@ inline void launch_dvr_lds(const VxParams& p, const DevVolume& v, const float4* 
   const bool phong = p.render_mode == VX_MODE_DVR_PHONG;
   const size_t tile_bytes = 4u * (size_t)(phong ? LdsTile<true>::FLOATS : LdsTile<false>::FLOATS) * sizeof(float);
   const size_t lds = (size_t)tf_len * sizeof(float4) + (skip ? (((size_t)v.skip_words + 3u) & ~(size_t)3u) * 4u : 0u) + tile_bytes;
-  constexpr int S = VX_LDS_S;
 #define VX_LAUNCH_LDS(PH, SK) \
-  hipLaunchKernelGGL((render_dvr_lds<S, PH, SK>), grid, block, lds, stream, p, v, tf, tf_len, mo, weight, tm, order)
+  hipLaunchKernelGGL((render_dvr_lds<(PH ? VX_LDS_S_PHONG : VX_LDS_S), PH, SK>), grid, block, lds, stream, p, v, tf, tf_len, mo, \
+                     weight, tm, order)
   if (phong) {
     if (skip) VX_LAUNCH_LDS(true, true); else VX_LAUNCH_LDS(true, false);
   } else {
