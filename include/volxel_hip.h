@@ -290,7 +290,10 @@ const char* vx_version(void);
 /* test hook: the integer RNG of shaders/random.glsl evaluated ON THE DEVICE (rows A1/A2), one thread per
  * output word.  op 0: out[i] = tea(a[i], b[i], 32) (random.glsl:41-51); op 1: out[i] = wangHash(a[i]) (:59-66);
  * op 2: out[0..n) = the first n xoshiro128pp_next words of seedXoshiro(a[0]) (:69-94, quirk Q1);
- * op 3: the same stream as rng() floats, bit patterns (:103-106).  a / b / out are host pointers.  */
+ * op 3: the same stream as rng() floats, bit patterns (:103-106);
+ * op 4: out[i] = how many of the 256 draws r = (256 * (a[0] + i) + j) / 2^24, j = 0..255, give a free-flight logarithm
+ * (the library's -log(1 - r), normal.glsl:13,28 / dda.glsl:28,58 / raymarch.glsl:26) that differs in any bit from
+ * -logf(1 - r): a[0] = 0, n = 65536 covers every value rng() can return.  a / b / out are host pointers.  */
 int vx_debug_rng(VxContext* ctx, int op, const uint32_t* a, const uint32_t* b, uint32_t n, uint32_t* out);
 
 /* measurement hook (no reference counterpart): what the vector L1 of this device sustains for the

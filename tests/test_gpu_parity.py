@@ -402,6 +402,9 @@ def test_device_rng_known_answers(oracle):
         assert np.array_equal(run(2, [seed], None, 300), raw)
         assert np.array_equal(run(3, [seed], None, 300), np.asarray(flt, dtype=np.float32).view(np.uint32))
     assert L.vx_debug_rng(r._ctx, 7, v0.ctypes.data, v1.ctypes.data, 4, v0.ctypes.data) != 0   # bad op
+    # the free flights' -log(1 - r) (logf's sequence without its denormal / infinity handling) against logf itself, for
+    # every one of the 2^24 values a draw can take
+    assert int(run(4, [0], None, 65536).astype(np.uint64).sum()) == 0
     r.close()
 
 

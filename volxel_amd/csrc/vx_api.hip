@@ -1568,7 +1568,7 @@ int vx_debug_build_skip_mask(const uint32_t* range_packed, const uint32_t brick_
 
 // test hook: random.glsl on the device
 int vx_debug_rng(VxContext* c, int op, const uint32_t* a, const uint32_t* b, uint32_t n, uint32_t* out) {
-  if (!c || !a || !out || n == 0 || n > 65536u || op < 0 || op > 3 || (op == 0 && !b)) return VX_ERR_INVALID;
+  if (!c || !a || !out || n == 0 || n > 65536u || op < 0 || op > 4 || (op == 0 && !b)) return VX_ERR_INVALID;
   VX_DEV(c);
   const uint32_t n_in = op < 2 ? n : 1u;
   uint32_t *da = nullptr, *db = nullptr, *dout = nullptr;

@@ -150,8 +150,9 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(VX_W_EVENTS
         if (DDA) {
           const V3 curr = madd3(ipos, t, idir);
           const int m = Frame<LAYOUT>::round_mip(mip);
-          majorant = fr.local_majorant(curr, m);
-          const float dt = Frame<LAYOUT>::step_dda(curr, ri, m);
+          const V3 cell = Frame<LAYOUT>::dda_cell(curr, m);
+          majorant = fr.local_majorant(cell, m);
+          const float dt = Frame<LAYOUT>::step_dda(curr, cell, ri, m);
           c.skips++;
           t += dt;
           tau = fma_(-majorant, dt, tau);

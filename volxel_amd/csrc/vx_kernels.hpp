@@ -461,7 +461,15 @@ __global__ __launch_bounds__(256) void debug_rng(int op, const uint32_t* __restr
                                                   uint32_t n, uint32_t* __restrict__ out) {
   uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n) return;
-  if (op == 0) {
+  if (op == 4) {
+    // 256 draws r = (256 * (a[0] + i) + j) / 2^24: how many free-flight logarithms differ in any bit from -logf(1 - r)
+    uint32_t bad = 0;
+    for (uint32_t j = 0; j < 256u; ++j) {
+      const float r = (float)(256u * (a[0] + i) + j) * 5.9604644775390625e-08f;
+      bad += __builtin_bit_cast(uint32_t, neg_log_one_minus(r)) != __builtin_bit_cast(uint32_t, -logf(1.0f - r));
+    }
+    out[i] = bad;
+  } else if (op == 0) {
     out[i] = tea32(a[i], b[i]);
   } else if (op == 1) {
     out[i] = wang_hash(a[i]);

@@ -85,26 +85,31 @@ struct Frame {
   }
 
   // ---- A13 default mode: sampling/dda.glsl ------------------------------------------
-  VXD static float step_dda(V3 pos, V3 inv_dir, int mip) {  // dda.glsl:11-16
-    float dim = (float)(8 << mip);
+  // The cell of the range-texture level `mip` that holds `pos` -- floor(pos / dim), dim = 8 << mip -- serves both halves of
+  // a DDA step: stepDDA's floor(pos * inv_dim) (dda.glsl:13) and the majorant look-up's ivec3(floor(pos)) >> (3 + mip)
+  // (common.glsl:50-53) are the same integer, because dim is a power of two (the product is exact) and
+  // floor(floor(x) / 2^k) == floor(x / 2^k).  One floor per axis instead of two, no shifts.
+  VXD static V3 dda_cell(V3 pos, int mip) {
     // 1 / dim: dim is a power of two, its reciprocal is the float with exponent -(3 + mip) -- no division sequence
-    float inv_dim = __builtin_bit_cast(float, (uint32_t)(124 - mip) << 23);
+    const float inv_dim = __builtin_bit_cast(float, (uint32_t)(124 - mip) << 23);
+    return v3(floorf(pos.x * inv_dim), floorf(pos.y * inv_dim), floorf(pos.z * inv_dim));
+  }
+  VXD static float step_dda(V3 pos, V3 cell, V3 inv_dir, int mip) {  // dda.glsl:11-16
+    float dim = (float)(8 << mip);
     float ox = (inv_dir.x >= 0.0f) ? dim + 0.5f : -0.5f;
     float oy = (inv_dir.y >= 0.0f) ? dim + 0.5f : -0.5f;
     float oz = (inv_dir.z >= 0.0f) ? dim + 0.5f : -0.5f;
-    float tx = ((floorf(pos.x * inv_dim) * dim + ox) - pos.x) * inv_dir.x;
-    float ty = ((floorf(pos.y * inv_dim) * dim + oy) - pos.y) * inv_dir.y;
-    float tz = ((floorf(pos.z * inv_dim) * dim + oz) - pos.z) * inv_dir.z;
+    float tx = ((cell.x * dim + ox) - pos.x) * inv_dir.x;
+    float ty = ((cell.y * dim + oy) - pos.y) * inv_dir.y;
+    float tz = ((cell.z * dim + oz) - pos.z) * inv_dir.z;
     return gl_min(tx, gl_min(ty, tz));
   }
   // dda.glsl:36,78: u_volume_maj * lookup_transfer(lookup_majorant(curr, mip) * inv_maj).a.  The value is a pure
   // function of the range-texture cell, the transfer function and four uniforms: vx_api tabulates it per cell with
   // these same operations (build_local_majorants), so a DDA step costs one load instead of the dependent chain
   // level dimensions -> range texel -> LUT entry.
-  VXD float local_majorant(V3 curr, int mip) const {
-    const int sh = 3 + mip;
-    const uint32_t bx = (uint32_t)(f2i(floorf(curr.x)) >> sh), by = (uint32_t)(f2i(floorf(curr.y)) >> sh),
-                   bz = (uint32_t)(f2i(floorf(curr.z)) >> sh);
+  VXD float local_majorant(V3 cell, int mip) const {
+    const uint32_t bx = (uint32_t)f2i(cell.x), by = (uint32_t)f2i(cell.y), bz = (uint32_t)f2i(cell.z);
     const bool in = bx < v.bc[0] && by < v.bc[1] && bz < v.bc[2];
     // 24-bit multiplies: at most 128 bricks per axis (brick.rs:77-81), four levels
     const uint32_t i = mad24_s(mad24_s(mad24_s((uint32_t)mip, v.bc[2], bz), v.bc[1], by), v.bc[0], bx);
@@ -123,8 +128,9 @@ struct Frame {
     while (t < far && (step++ < 100u)) {
       V3 curr = madd3(ipos, t, idir);
       int m = round_mip(mip);
-      float majorant = local_majorant(curr, m);
-      float dt = step_dda(curr, ri, m);
+      const V3 cell = dda_cell(curr, m);
+      float majorant = local_majorant(cell, m);
+      float dt = step_dda(curr, cell, ri, m);
       c.skips++;
       t += dt;
       tau = fma_(-majorant, dt, tau);
@@ -160,8 +166,9 @@ struct Frame {
     while (t < far && guard++ < LOOP_GUARD) {
       V3 curr = madd3(ipos, t, idir);
       int m = round_mip(mip);
-      float majorant = local_majorant(curr, m);
-      float dt = step_dda(curr, ri, m);
+      const V3 cell = dda_cell(curr, m);
+      float majorant = local_majorant(cell, m);
+      float dt = step_dda(curr, cell, ri, m);
       c.skips++;
       t += dt;
       tau = fma_(-majorant, dt, tau);
