@@ -386,10 +386,12 @@ VXD float lookup_transfer_alpha(const TfView& tf, const float sr0, const float s
 // fma, one compare and one band test replace the ten-instruction division sequence; when some lane of the wave falls
 // inside the band (about 3e-7 of the decisions) the stage is re-decided with the quotient itself, so every decision --
 // hence every tap, every sample and the RNG stream -- is the one the reference's expression gives.
-VXD bool reservoir_take(float r, float w, float sum, bool& unsure) {
-  const float m = gl_max(1e-3f, sum);
-  const float d = fma_(r, m, -w);
-  unsure = unsure | !(__builtin_fabsf(d) > m * 1.1920928955078125e-07f);
+// (max(1e-3, sum) is sum itself at every decision: the running sum holds the second weight, (3t^3 - 6t^2 + 4) / 6 >= 1/6,
+// from the first decision on.  The margin |d| - m * 2^-23 of the band test is returned; the caller tests the smallest of a
+// stage's three.  A NaN position makes every compare false here and in the reference expression alike.)
+VXD bool reservoir_take(float r, float w, float sum, float& margin) {
+  const float d = fma_(r, sum, -w);
+  margin = fma_(sum, -1.1920928955078125e-07f, __builtin_fabsf(d));
   return d < 0.0f;
 }
 VXD void stochastic_tricubic_filter(V3 ipos, Rng& s, int tap[3]) {
@@ -399,8 +401,9 @@ VXD void stochastic_tricubic_filter(V3 ipos, Rng& s, int tap[3]) {
   const float sixth = 1.0f / 6.0f;
 #pragma unroll
   for (int c = 0; c < 3; ++c) {
-    ii[c] = f2i(floorf(q[c]));
-    t[c] = q[c] - (float)ii[c];
+    const float fl = floorf(q[c]);
+    ii[c] = f2i(fl);
+    t[c] = q[c] - fl;   // == q - float(int(floor q)), the conversions cancel
     t2[c] = t[c] * t[c];
     w[c] = sixth * (fma_(-3.0f, t[c], fma_(3.0f, t2[c], -t[c] * t2[c])) + 1.0f);
     sum[c] = w[c];
@@ -415,9 +418,11 @@ VXD void stochastic_tricubic_filter(V3 ipos, Rng& s, int tap[3]) {
       sum[c] = w[c] + sum[c];
     }
     r[0] = rng(s); r[1] = rng(s); r[2] = rng(s);
-    bool unsure = false, take[3];
+    bool take[3];
+    float margin[3];
 #pragma unroll
-    for (int c = 0; c < 3; ++c) take[c] = reservoir_take(r[c], w[c], sum[c], unsure);
+    for (int c = 0; c < 3; ++c) take[c] = reservoir_take(r[c], w[c], sum[c], margin[c]);
+    const bool unsure = !(fminf(fminf(margin[0], margin[1]), margin[2]) > 0.0f);
     if (ballot(unsure) != 0ull) {   // wave uniform, rare: the reference's expression itself
 #pragma unroll
       for (int c = 0; c < 3; ++c) take[c] = r[c] < w[c] / gl_max(1e-3f, sum[c]);
