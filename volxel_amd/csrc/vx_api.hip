@@ -631,6 +631,7 @@ static int alloc_layout(VxContext* c, uint32_t& n_layers) {
     (void)hipFree(c->bf_alloc);
     c->bf_alloc = nullptr;
     c->dv.bf = nullptr;
+    c->dv.bf_zero = 0;
   }
   n_layers = 0;
   c->auto_no_cq = c->auto_no_bf = false;
@@ -651,6 +652,7 @@ static int alloc_layout(VxContext* c, uint32_t& n_layers) {
     VX_HIP(c, hipMalloc(&c->bf_alloc, n_vox * sizeof(float) + 16));
     VX_HIP(c, hipMemsetAsync((char*)c->bf_alloc + n_vox * sizeof(float), 0, 16, c->stream));
     c->dv.bf = (const float*)c->bf_alloc;
+    c->dv.bf_zero = n_vox <= 0xfffffff0ull ? (uint32_t)n_vox : 0u;
     n_layers = c->dv.bc[2];
     return VX_OK;
   }
@@ -703,6 +705,7 @@ static int ensure_brickf32(VxContext* c) {
   VX_HIP(c, hipMalloc(&c->bf_alloc, n_vox * sizeof(float) + 16));   // + the zero chunk (alloc_layout)
   VX_HIP(c, hipMemsetAsync((char*)c->bf_alloc + n_vox * sizeof(float), 0, 16, c->stream));
   c->dv.bf = (const float*)c->bf_alloc;
+  c->dv.bf_zero = n_vox <= 0xfffffff0ull ? (uint32_t)n_vox : 0u;
   for (uint64_t at = 0; at < n_vox;) {
     uint64_t n = n_vox - at < (1ull << 31) ? n_vox - at : (1ull << 31);
     hipLaunchKernelGGL(build_brickf32, dim3((uint32_t)((n + 255) / 256)), dim3(256), 0, c->stream, c->dv,

@@ -33,7 +33,8 @@ struct DevVolume {
   const float4* cq;             // [(bc+1)^3][9 slices][8][8] float4
   uint32_t cq_bc[3];            // bc + 1
   // MI355X layout "brickf32": every 8^3 brick decoded to fp32, 2 KiB contiguous, brick-major
-  const float* bf;              // [bc.z][bc.y][bc.x][8][8][8]
+  const float* bf;              // [bc.z][bc.y][bc.x][8][8][8], one all-zero 16-byte chunk behind the last brick
+  uint32_t bf_zero;             // index (in floats) of that chunk, or 0 when the layout needs more than 32 index bits
   // exact empty-space skipping (DVR): one bit per macro cell of 8 << skip_level voxels
   const uint32_t* skip_bits;    // nullptr: none
   uint32_t skip_level;
@@ -256,6 +257,14 @@ enum { LAYOUT_REF = 0, LAYOUT_CQ = 1, LAYOUT_BF = 2 };
 // decoded voxel from the brickf32 layout; out-of-range taps are 0; straight-line as above
 VXD float bf_voxel(const DevVolume& v, int x, int y, int z) {
   const bool in = (uint32_t)x < v.extent[0] && (uint32_t)y < v.extent[1] && (uint32_t)z < v.extent[2];
+  if (v.bf_zero != 0u) {   // wave uniform; every volume below 2^32 voxels of layout (about 1600^3)
+    // a voxel outside the volume reads the zero chunk behind the last brick: one select on the index -- no clamps, no
+    // select on the value (its index is formed from the raw coordinates, wraps, and is dropped)
+    const uint32_t ux = (uint32_t)x, uy = (uint32_t)y, uz = (uint32_t)z;
+    const uint32_t b = mad24_s(mad24_s(uz >> 3, v.bc[1], uy >> 3), v.bc[0], ux >> 3);
+    const uint32_t l = ((uz & 7u) << 6) | ((uy & 7u) << 3) | (ux & 7u);
+    return v.bf[in ? (b << 9) | l : v.bf_zero];
+  }
   const uint32_t ux = (uint32_t)clamp0_i32(x, (int)v.extent[0] - 1), uy = (uint32_t)clamp0_i32(y, (int)v.extent[1] - 1),
                  uz = (uint32_t)clamp0_i32(z, (int)v.extent[2] - 1);
   const uint32_t b = ((uz >> 3) * v.bc[1] + (uy >> 3)) * v.bc[0] + (ux >> 3);
