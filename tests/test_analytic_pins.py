@@ -223,3 +223,31 @@ def test_trilinear_reproduces_a_linear_field(oracle):
     brick_range = 12.0 * 60.0 / vmax
     assert worst <= 0.5 * brick_range / 255.0 + 2.0 ** -11 + 1e-6, worst
     assert worst < 0.25 * 10.0 / vmax * 2.5          # far below what a half-voxel shift along the slowest axis would give (5 / vmax)
+
+
+def test_trilinear_against_scipy_on_random_data(oracle):
+    """A4 + A5 against third-party code on data with no structure: the decoded voxels (vxo_lookup_density_brick, tap by
+    tap) interpolated by scipy.ndimage.map_coordinates (order 1, grid-constant zero padding -- the oracle rule for taps beyond the
+    volume) must agree with vxo_lookup_density_trilinear at random continuous positions, faces and corners included.
+    scipy's interpolation shares no code with the oracle or the kernels: a wrong tap order, weight or offset shows as
+    an error of the order of the data's contrast, not of fp32 rounding."""
+    ndimage = pytest.importorskip("scipy.ndimage")
+    L = oracle.lib()
+    rng = np.random.default_rng(11)
+    vox = rng.integers(0, 4096, size=(19, 27, 33), dtype=np.uint16)      # ragged: padded to 24 x 32 x 40
+    g = oracle.BrickGrid(vox, (1.0, 1.0, 1.0))
+    vol = oracle.make_volume(g)
+    nz, ny, nx = vox.shape
+    ez, ey, ex = [8 * ((n + 7) // 8) for n in (nz, ny, nx)]              # the padded extent the index space spans
+    dec = np.zeros((ez, ey, ex), dtype=np.float64)
+    for z in range(ez):
+        for y in range(ey):
+            for x in range(ex):
+                dec[z, y, x] = L.vxo_lookup_density_brick(vol, x, y, z)
+    pts = rng.uniform(-0.75, 1.0, size=(600, 3)) * np.array([ex, ey, ez]) + rng.uniform(0, 1, size=(600, 3))
+    pts = np.concatenate([pts, [[0.0, 0.0, 0.0], [0.5, 0.5, 0.5], [ex, ey, ez], [ex - 0.5, 0.5, ez - 0.5], [nx - 0.25, ny + 0.25, 3.5]]])
+    # voxel centres at integer + 1/2: array coordinate = p - 1/2, in (z, y, x) order
+    want = ndimage.map_coordinates(dec, [pts[:, 2] - 0.5, pts[:, 1] - 0.5, pts[:, 0] - 0.5], order=1, mode="grid-constant", cval=0.0)
+    got = np.array([L.vxo_lookup_density_trilinear(vol, 1.0, float(p[0]), float(p[1]), float(p[2])) for p in pts])
+    assert np.abs(dec).max() > 0.5 and np.abs(got).max() > 0.3          # there is contrast to get wrong
+    assert np.abs(got - want).max() <= 2e-6, np.abs(got - want).max()
