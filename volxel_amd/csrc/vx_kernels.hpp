@@ -203,13 +203,36 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(generic_min
   uint32_t lt, sub;
   if (!block_to_tile(blk, tm, lt, sub)) return;
   uint32_t wt = sub * 4u + (threadIdx.x >> 6), lane = threadIdx.x & 63u;
+  uint32_t my_frame = frame;
+  // Path-traced modes in a multi-frame launch: a wave takes 64 / FW pixels of its 8x8 tile for FW frames of the launch
+  // instead of 64 pixels of one frame (FW = 8, or 4 / 2 when the launch's frame count only divides by that).  The FW
+  // waves that shared the tile, one per frame slot, now share it by pixel subset: wave j of the group renders Morton
+  // pixels j * P .. j * P + P - 1 for every frame of the group.  Each (pixel, frame) is computed exactly as before (its
+  // seed is tea(pixel, frame), fragment.frag:143) and written to its frame's slab, so results are bit-identical; but the
+  // free-flight samples of one wave now fall along a beam P pixels wide instead of 64, and the vector L1 -- whose misses
+  // in flight bound these modes -- serves more of them: no_dda 0.684 -> 0.622 ms per frame.
+  if (MODE <= VX_MODE_RAYMARCH && mo.count > 1u) {   // wave uniform
+    const uint32_t sh = (mo.count & 7u) == 0u ? 3u : (mo.count & 3u) == 0u ? 2u : (mo.count & 1u) == 0u ? 1u : 0u;
+    if (sh != 0u) {
+      const uint32_t psh = 6u - sh, j = fslot & ((1u << sh) - 1u);
+      const uint32_t my_fslot = fslot - j + (lane >> psh);
+      lane = (j << psh) + (lane & ((1u << psh) - 1u));
+      // the frame slot is per lane now: read its slab pointer and frame index from the kernel-argument segment (indexing
+      // the by-value MultiOut with a lane-varying index would copy all of it to scratch)
+      struct KArgs { VxParams p; DevVolume v; const float4* tf; uint32_t tf_len; MultiOut mo; };   // the argument list
+      typedef const char __attribute__((address_space(4)))* KPtr;
+      const KPtr ka = (KPtr)__builtin_amdgcn_kernarg_segment_ptr() + offsetof(KArgs, mo);
+      slab = ((float4* const __attribute__((address_space(4)))*)(ka + offsetof(MultiOut, out)))[my_fslot];
+      my_frame = ((const uint32_t __attribute__((address_space(4)))*)(ka + offsetof(MultiOut, frame)))[my_fslot];
+    }
+  }
   int px, py;
   uint32_t si;
   bool active = wave_pixel(tm, lt, wt, lane, px, py, si);
   Counts c{0, 0, 0, 0, 0};
   if (active) {
     Frame<LAYOUT> f{p, v, tf, c};
-    float4 r = f.template shade_pixel<MODE>(px, py, frame);
+    float4 r = f.template shade_pixel<MODE>(px, py, my_frame);
     float4 prev = make_float4(0.f, 0.f, 0.f, 0.f);
     if (weight != 0.0f) prev = slab[si];
     // fragment.frag:158  out = (w*prev + (1-w)*result).rgb, alpha 1
