@@ -152,12 +152,25 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(PHONG ? (SK
   uint32_t lt, sub;
   if (!block_to_tile(blk, tm, lt, sub)) return;
   const uint32_t wt = sub * 4u + (threadIdx.x >> 6), lane = threadIdx.x & 63u;
+  uint32_t plane = lane, my_frame = frame;
+#ifndef VX_DVR_FL_MAXSH
+#define VX_DVR_FL_MAXSH 3
+#endif
+  if (mo.count > 1u) {   // lanes = pixels x frames (vx_kernels.hpp frame_group)
+    uint32_t base;
+    const uint32_t sh = frame_group<VX_DVR_FL_MAXSH>(fslot, mo.count, base);
+    if (sh != 0u) {
+      const uint32_t psh = 6u - sh;
+      plane = ((fslot - base) << psh) + (lane & ((1u << psh) - 1u));
+      slab = lane_frame_slot(base + (lane >> psh), my_frame);
+    }
+  }
   int px, py;
   uint32_t si;
-  const bool in_image = wave_pixel(tm, lt, wt, lane, px, py, si);
+  const bool in_image = wave_pixel(tm, lt, wt, plane, px, py, si);
 
   DvrRay r{};
-  if (in_image) r = dvr_setup(p, px, py, frame);
+  if (in_image) r = dvr_setup(p, px, py, my_frame);
   const bool hit0 = in_image && r.hit;
   const uint32_t n_rays = (uint32_t)__builtin_popcountll(ballot(hit0));
   // samples the lane's ray still has: k = 0 .. nray - 1 (march contract, vx_dvr.hpp); a ray that terminates early

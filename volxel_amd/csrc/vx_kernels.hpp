@@ -153,6 +153,40 @@ VXD void multi_slot(uint32_t p, uint32_t count, uint32_t& fslot, uint32_t& bslot
 #endif
 }
 
+// Lanes = pixels x frames (multi-frame launches).  The frame slots of a launch are cut into groups of 2^sh consecutive
+// slots, the largest power of two first (20 slots, MAXSH 3: 8 + 8 + 4); the 2^sh waves that would each render the 64
+// pixels of one 8x8 wave tile for one slot of the group render 64 >> sh pixels of it for all slots of the group instead:
+// hardware lane l of the wave at slot `fslot` takes frame slot base + (l >> (6 - sh)) and Morton pixel
+// ((fslot - base) << (6 - sh)) + (l & ((64 >> sh) - 1)).  Every (pixel, frame) of the launch is rendered exactly once,
+// by the same arithmetic as before (its seed is tea(pixel, frame), fragment.frag:143), and stored to its frame's slab:
+// results are bit-identical; what changes is that the rays of a wave are 64 >> sh neighbouring pixels seen 2^sh times
+// under different jitter -- a beam a few voxels wide that the lanes walk in step.
+template <int MAXSH>
+VXD uint32_t frame_group(uint32_t fslot, uint32_t count, uint32_t& base) {   // wave uniform; returns sh
+  base = 0u;
+#pragma unroll
+  for (int sh = MAXSH; sh > 0; --sh) {
+    const uint32_t full = (count - base) >> sh;
+    if (fslot < base + (full << sh)) {
+      base += ((fslot - base) >> sh) << sh;
+      return (uint32_t)sh;
+    }
+    base += full << sh;
+  }
+  base = fslot;
+  return 0u;
+}
+// the slab pointer and frame index of a lane's own frame slot, read from the kernel-argument segment (indexing the
+// by-value MultiOut with a lane-varying index would copy all of it to scratch).  Both render kernels that use it start
+// their argument list with (VxParams, DevVolume, const float4*, uint32_t, MultiOut).
+VXD float4* lane_frame_slot(uint32_t my_fslot, uint32_t& frame) {
+  struct KArgs { VxParams p; DevVolume v; const float4* tf; uint32_t tf_len; MultiOut mo; };
+  typedef const char __attribute__((address_space(4)))* KPtr;
+  const KPtr ka = (KPtr)__builtin_amdgcn_kernarg_segment_ptr() + offsetof(KArgs, mo);
+  frame = ((const uint32_t __attribute__((address_space(4)))*)(ka + offsetof(MultiOut, frame)))[my_fslot];
+  return ((float4* const __attribute__((address_space(4)))*)(ka + offsetof(MultiOut, out)))[my_fslot];
+}
+
 // Occupancy the register allocator is asked for, per mode.  The path-traced modes are bound by latency and
 // divergence (about 37 % of the lane slots of an issued VALU instruction do work), so more resident waves
 // pay even at the price of a few spills: measured on config 3 (tools/variant_modes.sh, ms per frame, 32 frames
@@ -204,19 +238,16 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(generic_min
   if (!block_to_tile(blk, tm, lt, sub)) return;
   uint32_t wt = sub * 4u + (threadIdx.x >> 6), lane = threadIdx.x & 63u;
   uint32_t my_frame = frame;
-  // Path-traced modes in a multi-frame launch: a wave takes 64 / FW pixels of its 8x8 tile for FW frames of the launch
-  // instead of 64 pixels of one frame (FW = 8, or 4 / 2 when the launch's frame count only divides by that).  The FW
-  // waves that shared the tile, one per frame slot, now share it by pixel subset: wave j of the group renders Morton
-  // pixels j * P .. j * P + P - 1 for every frame of the group.  Each (pixel, frame) is computed exactly as before (its
-  // seed is tea(pixel, frame), fragment.frag:143) and written to its frame's slab, so results are bit-identical; but the
-  // free-flight samples of one wave now fall along a beam P pixels wide instead of 64, and the vector L1 -- whose misses
-  // in flight bound these modes -- serves more of them: no_dda 0.684 -> 0.622 ms per frame.
+  // Path-traced modes in a multi-frame launch: lanes = pixels x frames (frame_group above), 8 pixels x 8 frames per wave.
+  // The free-flight samples of one wave then fall along a beam 8 pixels wide instead of 64, and the vector L1 -- whose
+  // misses in flight bound these modes -- serves more of them: no_dda 0.684 -> 0.622 ms per frame.
   if (MODE <= VX_MODE_RAYMARCH && mo.count > 1u) {   // wave uniform
-    const uint32_t sh = (mo.count & 7u) == 0u ? 3u : (mo.count & 3u) == 0u ? 2u : (mo.count & 1u) == 0u ? 1u : 0u;
+    uint32_t base;
+    const uint32_t sh = frame_group<3>(fslot, mo.count, base);
     if (sh != 0u) {
       const uint32_t psh = 6u - sh;
-      uint32_t j = fslot & ((1u << sh) - 1u);
-      uint32_t my_fslot = fslot - j + (lane >> psh);
+      uint32_t j = fslot - base;
+      uint32_t my_fslot = base + (lane >> psh);
       // with 32 frames to share out, the four waves of a workgroup take the SAME 8 pixels (8 frames each) instead of four
       // pixel groups of four tiles: 8 beams per CU instead of 32 (no_dda 0.623 -> 0.606 ms per frame)
       if ((mo.count & 31u) == 0u) {
@@ -226,13 +257,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(generic_min
         my_fslot = (fslot - r) + (threadIdx.x >> 6) * 8u + (lane >> 3);
       }
       lane = (j << psh) + (lane & ((1u << psh) - 1u));
-      // the frame slot is per lane now: read its slab pointer and frame index from the kernel-argument segment (indexing
-      // the by-value MultiOut with a lane-varying index would copy all of it to scratch)
-      struct KArgs { VxParams p; DevVolume v; const float4* tf; uint32_t tf_len; MultiOut mo; };   // the argument list
-      typedef const char __attribute__((address_space(4)))* KPtr;
-      const KPtr ka = (KPtr)__builtin_amdgcn_kernarg_segment_ptr() + offsetof(KArgs, mo);
-      slab = ((float4* const __attribute__((address_space(4)))*)(ka + offsetof(MultiOut, out)))[my_fslot];
-      my_frame = ((const uint32_t __attribute__((address_space(4)))*)(ka + offsetof(MultiOut, frame)))[my_fslot];
+      slab = lane_frame_slot(my_fslot, my_frame);
     }
   }
   int px, py;
