@@ -1,5 +1,5 @@
 #!/bin/bash
-# rocprofv3 evidence for BASELINE config 4 (DVR + gradient + Blinn-Phong, render_dvr_lds<12,true,.>): kernel trace with
+# rocprofv3 evidence for BASELINE config 4 (DVR + gradient + Blinn-Phong, render_dvr_lds<16,true,.>): kernel trace with
 # stats, then counter passes (counters only) -> gpurun_out/prof/<tag>; summary: python tools/phong_summary.py <dir>
 cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
 TAG=${1:-r02_phong}

@@ -3,9 +3,9 @@
 import csv, glob, os, sys
 from collections import defaultdict
 root = sys.argv[1]
-KERN = "render_dvr_lds<12, true"
+KERN = "render_dvr_lds<16, true"
 print("# rocprofv3 evidence for BASELINE config 4 (config 3 + central-difference gradient + Blinn-Phong): kernel")
-print("# vx::render_dvr_lds<12, true, false>, 1080p, jitter on, 16 frames per launch (tools/phong_pmc.sh, tools/mode_profile.py)")
+print("# vx::render_dvr_lds<16, true, false>, 1080p, jitter on, 16 frames per launch (tools/phong_pmc.sh, tools/mode_profile.py)")
 for f in glob.glob(os.path.join(root, "*.log")):
     for ln in open(f):
         if ln.startswith("dvr_phong"):

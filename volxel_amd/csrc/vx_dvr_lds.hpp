@@ -49,8 +49,8 @@ namespace vx {
 #ifndef VX_LDS_S
 #define VX_LDS_S 16
 #endif
-#ifndef VX_LDS_S_PHONG   // steps per window of the shading kernel (12 / 16 / 20 / 24: 0.365 / 0.370 / 0.375 / 0.377 ms per frame)
-#define VX_LDS_S_PHONG 12
+#ifndef VX_LDS_S_PHONG   // steps per window of the shading kernel: with one frame's 64 pixels per wave 12 / 16 / 20 / 24 gave
+#define VX_LDS_S_PHONG 16  // 0.365 / 0.370 / 0.375 / 0.377 ms per frame; with lanes = pixels x frames 12 / 16 / 20: 0.335 / 0.327 / 0.329
 #endif
 template <bool PHONG>
 struct LdsTile {
