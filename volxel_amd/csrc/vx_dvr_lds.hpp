@@ -462,8 +462,10 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(PHONG ? (SK
     bool more;
     bool go = kf < klim;     // carried: the bottom test of one trip is the lane mask of the next
     unsigned long long gom = ballot(go);   // the same as a scalar (the ballot of a carried bool would be materialised)
-#pragma unroll 1
-    do {
+    // one step of the wave.  ALL: every lane of the wave steps (the common case since a wave's lanes are a few pixels
+    // under many frames' jitter): no select on the tile address or on the step count
+    auto step = [&](auto all_tag) {
+      constexpr bool ALL = decltype(all_tag)::value;
       n_slots += 64u;
       bool eval = go;
       float jump = 0.0f;   // SKIP: further steps this lane may pass over (all inside the same empty macro cell)
@@ -481,7 +483,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(PHONG ? (SK
       // integer below 2^23, exact in fp32 (cells are below 2^13, the byte strides below 2^11).  A lane that does not step (its pending sample
       // lies outside this window) reads the tile's first cell instead: every read stays inside the wave's tile.
       const int cell_addr = (int)fma_(flz, (float)(4 * SS), fma_(fly, (float)(4 * RS), fma_(flx, 4.0f, tile_base)));
-      const int addr = go ? cell_addr : tile_addr;
+      const int addr = ALL ? cell_addr : (go ? cell_addr : tile_addr);
       const LdsFloatPtr tp = (LdsFloatPtr)(uintptr_t)(uint32_t)addr;
       const LdsFloatPtr tq = tp + SS;             // slice z + 1
       const float v000 = tp[0], v100 = tp[1], v010 = tp[RS], v110 = tp[RS + 1];
@@ -570,13 +572,33 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(PHONG ? (SK
         klim = tau >= ert ? 0.0f : klim;
       }
       // the lanes that stepped move on to their next sample (the others recompute the position they already hold)
-      kf = go ? kf + 1.0f + jump : kf;
+      kf = ALL ? kf + 1.0f : (go ? kf + 1.0f + jump : kf);
       next_sample();
       ++s;
       go = kf < klim;
       gom = ballot(go);
-      more = (s < S) & (gom != 0ull);   // somebody can still step in this window
-    } while (more);
+    };
+#ifndef VX_NO_ALL_LANES_LOOP
+    if (!TEST) {
+      const unsigned long long full = ballot(true);   // the wave's lanes (all 64 unless the grid's last wave is ragged)
+      bool fast = gom == full;
+      if (fast) {
+#pragma unroll 1
+        do {
+          step(std::true_type{});
+          fast = (gom == full) & (s < S);
+        } while (fast);
+      }
+    }
+#endif
+    more = (s < S) & (gom != 0ull);   // somebody can still step in this window
+    if (more) {
+#pragma unroll 1
+      do {
+        step(std::false_type{});
+        more = (s < S) & (gom != 0ull);
+      } while (more);
+    }
   };
   while (true) {
     if (ballot(is_alive()) == 0ull) break;
