@@ -561,6 +561,37 @@ int vx_create(int device_id, VxContext** out) {
     return VX_ERR_DEVICE;
   }
   c->stream = c->own_stream;
+  {
+    // lanes = pixels x frames (vx_kernels.hpp frame_group) reads per-lane frame slots from the kernel-argument segment
+    // at the offsets of struct KArgs: check once per context that the compiler lays the arguments out that way
+    VxParams tp{};
+    DevVolume tv{};
+    MultiOut tm{};
+    tp.res[0] = 0x1234;
+    tv.extent[0] = 0x5678u;
+    for (uint32_t i = 0; i < (uint32_t)MERGE_MAX; ++i) {
+      tm.out[i] = reinterpret_cast<float4*>((uintptr_t)0x100000000ull * (i + 3u) + 16u * i);
+      tm.frame[i] = 0xabc00000u + 7u * i;
+    }
+    tm.count = MERGE_MAX;
+    uint32_t* bad = nullptr;
+    uint32_t hbad = 1;
+    hipError_t ce = hipMalloc(&bad, 4);
+    if (ce == hipSuccess) {
+      hipLaunchKernelGGL(check_lane_frame_slot, dim3(1), dim3(64), 0, c->stream, tp, tv, (const float4*)nullptr, 0x9abcu, tm, bad);
+      ce = hipGetLastError();
+    }
+    if (ce == hipSuccess) ce = hipMemcpyAsync(&hbad, bad, 4, hipMemcpyDeviceToHost, c->stream);
+    if (ce == hipSuccess) ce = hipStreamSynchronize(c->stream);
+    if (bad) (void)hipFree(bad);
+    if (ce != hipSuccess || hbad != 0u) {
+      g_create_error = ce != hipSuccess ? "vx_create: device self-check failed to run"
+                                        : "vx_create: kernel-argument layout differs from struct KArgs (lane_frame_slot)";
+      (void)hipStreamDestroy(c->own_stream);
+      delete c;
+      return VX_ERR_DEVICE;
+    }
+  }
   const char* v = getenv("VX_DVR_KERNEL");
   if (v && !strcmp(v, "generic")) c->dvr_variant = 0;
   const char* pk = getenv("VX_PATHS_KERNEL");

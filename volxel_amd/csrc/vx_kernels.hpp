@@ -187,6 +187,24 @@ VXD float4* lane_frame_slot(uint32_t my_fslot, uint32_t& frame) {
   return ((float4* const __attribute__((address_space(4)))*)(ka + offsetof(MultiOut, out)))[my_fslot];
 }
 
+// vx_create's check of lane_frame_slot: a kernel with the render kernels' argument list reads every frame slot through the
+// kernel-argument segment and compares with the by-value struct; *bad counts the slots that differ (0 unless the
+// compiler's argument layout ever stops matching struct KArgs)
+__global__ __launch_bounds__(64) void check_lane_frame_slot(const VxParams p, const DevVolume v, const float4* __restrict__ tf,
+                                                            uint32_t tf_len, const MultiOut mo, uint32_t* __restrict__ bad) {
+  const uint32_t lane = threadIdx.x;
+  uint32_t frame = 0;
+  float4* slab = lane_frame_slot(lane, frame);   // lane-varying index: a vector load from the argument segment
+  uint32_t differs = 0;
+  for (uint32_t i = 0; i < (uint32_t)MERGE_MAX; ++i) {   // uniform index: the compiler's own view of the argument
+    const uint32_t f = (uint32_t)__builtin_amdgcn_readlane((int)frame, (int)i);
+    const uint64_t s = ((uint64_t)(uint32_t)__builtin_amdgcn_readlane((int)((uint64_t)(uintptr_t)slab >> 32), (int)i) << 32) |
+                       (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)(uintptr_t)slab, (int)i);
+    differs += (f != mo.frame[i]) | (s != (uint64_t)(uintptr_t)mo.out[i]);
+  }
+  if (lane == 0) *bad = differs + (p.res[0] != 0x1234) + (v.extent[0] != 0x5678u) + (tf_len != 0x9abcu) + (tf != nullptr);
+}
+
 // Occupancy the register allocator is asked for, per mode.  The path-traced modes are bound by latency and
 // divergence (about 37 % of the lane slots of an issued VALU instruction do work), so more resident waves
 // pay even at the price of a few spills: measured on config 3 (tools/variant_modes.sh, ms per frame, 32 frames
