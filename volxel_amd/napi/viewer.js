@@ -446,8 +446,9 @@ class Volxel3DDicomRenderer {
     return p;
   }
 
-  /** frames accumulation samples; inFlight > 1 renders that many per launch (same bits, vx_render_frames) */
-  render(frames = 1, inFlight = 1) { // viewer.ts:1183-1293
+  /** frames accumulation samples, up to inFlight of them per launch (vx_render_frames: same bits as one launch per
+   *  frame, 1.6x the speed at 32) */
+  render(frames = 1, inFlight = 32) { // viewer.ts:1183-1293
     const weight = f => (f < LOW_RES_DURATION ? 0 : (f - LOW_RES_DURATION) / (f - LOW_RES_DURATION + 1)); // viewer.ts:1356
     let bound = false;
     for (let i = 0; i < frames && this.frameIndex <= this.settings.maxSamples;) {
