@@ -17,11 +17,11 @@ run() {  # note, args...
   echo "ok: $*"
 }
 LEAN="--no-cpu-baseline --no-mode-variants --no-skip-variant"
-run "the driver's command" --gpus 1 --steps 20 --warmup 5 &&
-run "32 frames per launch: 4 launches" --steps 128 --warmup 5 --no-cpu-baseline &&
-run "64 frames per launch" --steps 128 --warmup 5 --frames-per-launch 64 $LEAN &&
+run "the driver's command: 20 steps of 32 accumulation frames, one launch each" --gpus 1 --steps 20 --warmup 5 &&
+run "64 frames per launch" --steps 20 --warmup 5 --frames-per-launch 64 $LEAN &&
+run "one frame per step, the step of rounds 1-2: a single 20-frame launch is timed" --steps 20 --warmup 5 --frames-per-step 1 $LEAN &&
+run "the same after 150 ms of device preconditioning (value) and before it (value_cold)" --steps 20 --warmup 5 --frames-per-step 1 --precondition-ms 150 $LEAN &&
 run "cellquad gather kernel" --gpus 1 --steps 20 --warmup 5 --layout 1 $LEAN &&
 run "BASELINE config 5 workload, whole frame on one GPU" --volume 1024 --width 3840 --height 2160 --steps 20 --warmup 5 --no-cpu-baseline --no-mode-variants &&
-run "config 5 workload, cellquad gather kernel" --volume 1024 --width 3840 --height 2160 --steps 20 --warmup 5 --layout 1 $LEAN &&
-run "RCCL gather path with one rank" --gpus 1 --steps 20 --warmup 5 --force-gather $LEAN &&
-run "the driver's command without device preconditioning: the chip still at its idle clocks" --gpus 1 --steps 20 --warmup 5 --precondition-ms 0 $LEAN
+run "config 5 workload, cellquad gather kernel" --volume 1024 --width 3840 --height 2160 --steps 10 --warmup 2 --layout 1 $LEAN &&
+run "RCCL gather path with one rank" --gpus 1 --steps 20 --warmup 5 --force-gather $LEAN
