@@ -409,18 +409,6 @@ def main():
         cold = {"elapsed": cold_elapsed, "samples": cold_c.samples}
         r.restart_rendering()
         r.bind_uniforms()
-    # (2) the fixed cost of a timed region that renders nothing: snapshot copy + all_gather + the fences
-    fixed_ms = None
-    if use_dist:
-        fence()
-        tf0 = time.perf_counter()
-        gather()
-        fence()
-        fixed_ms = (time.perf_counter() - tf0) * 1e3
-        if use_dist:
-            t = torch.tensor([fixed_ms], dtype=torch.float64, device="cuda")
-            dist.all_reduce(t, op=dist.ReduceOp.MAX)
-            fixed_ms = float(t.item())
     # device preconditioning: the chip idled while the host generated the volume; a few ms of warm-up steps do not
     # bring it back to the clock it sustains under load (measured: 0.36 instead of 0.31 ms per frame)
     pre = {"frames": 0, "seconds": 0.0}
@@ -435,6 +423,21 @@ def main():
         r.bind_uniforms()
 
     elapsed, c = timed(0)
+    n_gathers = state["gathers"]
+
+    # the fixed cost of a timed region that renders nothing: snapshot copy + all_gather + the fences (measured straight
+    # after the timed run: device and RCCL in the state the timed region had them)
+    fixed_ms = None
+    if use_dist:
+        fence()
+        tf0 = time.perf_counter()
+        gather()
+        fence()
+        fixed_ms = (time.perf_counter() - tf0) * 1e3
+        if use_dist:
+            t = torch.tensor([fixed_ms], dtype=torch.float64, device="cuda")
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            fixed_ms = float(t.item())
 
     samples, pixels = c.samples, c.pixels
     cold_samples = cold["samples"] if cold else 0
@@ -529,7 +532,7 @@ def main():
                                 f"{'cost-balanced dealing order' if (world > 1 and not a.no_balance) else 'round-robin'}, volume replicated, RCCL "
                                 f"all_gather of the framebuffer every {a.gather_every} frames, overlapped)")
                                if use_dist else "1 GPU",
-                "gathers": state["gathers"],
+                "gathers": n_gathers,
                 "layout": LAYOUT[a.layout],
                 "frames_per_step": F, "frames_timed": frames_timed,
                 "samples_per_frame": int(samples // frames_timed),

@@ -32,7 +32,8 @@ for f in newest(os.path.join(root, "kt", "**", "*kernel_trace.csv")):
     for row in csv.DictReader(open(f)):
         if kern in row.get("Kernel_Name", ""):
             by[int(row["Grid_Size_X"]) if "Grid_Size_X" in row else int(row.get("Grid_Size", 0))].append(
-                (int(row["End_Timestamp"]) - int(row["Start_Timestamp"])) / 1e6)
+                (int(row["Start_Timestamp"]), (int(row["End_Timestamp"]) - int(row["Start_Timestamp"])) / 1e6))
+    by = defaultdict(list, {g: [d for _, d in sorted(v)] for g, v in by.items()})   # durations in launch order
     print("\n## kernel trace of '" + kern + "' by launch size (threads in x): calls, mean ms, min, max")
     for g, v in sorted(by.items()):
         print(f"grid {g:10d}: {len(v):3d} calls, mean {sum(v)/len(v):8.4f} ms, min {min(v):8.4f}, max {max(v):8.4f}")
@@ -51,11 +52,19 @@ if line and by:
     g1 = min(by)
     gt = g1 * fpl if g1 * fpl in by else max(by)
     v = by[gt]
+    # launches of this shape in order: [cold pass], warm-up launches, the timed ones, then side measurements
+    n_timed = int(line["roofline"]["launches"])
+    fps = int(line["config"].get("frames_per_step", 1))
+    n_warm = -(-max(int(line["warmup"]) * fps, 2) // fpl)
+    first = n_warm + ((n_warm + n_timed) if line.get("value_cold") else 0)
+    tv = v[first:first + n_timed] if len(v) >= first + n_timed else v
     print("\n## the timed launches")
-    print(f"The --stats average above mixes every launch of the kernel: device preconditioning and the other untimed")
-    print(f"launches (other frames per launch), warm-up, the single-frame side measurement.  bench.py timed the {len(v)} launch(es)")
-    print(f"of {fpl} frames = grid {gt}: kernel trace mean {sum(v)/len(v):.4f} ms; bench.py (HIP events, same run) "
+    print(f"The --stats average above mixes every launch of the kernel: the warm-up steps (the first one runs on a chip at")
+    print(f"its idle clocks), other frames per launch, the single-frame side measurement.  In launch order the {len(v)} launches of")
+    print(f"{fpl} frames = grid {gt} are {n_warm} warm-up + {n_timed} timed + the rest; the {len(tv)} timed ones: kernel trace mean "
+          f"{sum(tv)/len(tv):.4f} ms (min {min(tv):.4f}, max {max(tv):.4f}); bench.py (HIP events, same run) "
           f"roofline.avg_kernel_ms {line['roofline']['avg_kernel_ms']}")
+    by[gt] = tv
 print("\n## PMC counters: per-dispatch mean over the timed dispatches of the kernel")
 means = {}
 for d in sorted(glob.glob(os.path.join(root, "*"))):
