@@ -55,8 +55,16 @@ namespace vx {
 template <bool PHONG>
 struct LdsTile {
   static constexpr int X = VX_LDS_X;             // X / 4 chunks of 16 bytes per row
-  static constexpr int Y = PHONG ? VX_LDS_DP : VX_LDS_D;
-  static constexpr int Z = PHONG ? VX_LDS_DP : VX_LDS_D;
+#ifndef VX_LDS_DY   // windows that are not square in (y, z), with lanes = pixels x frames, config 3, ms per frame at 32 frames per
+                    // launch: 8x8 0.2098, 6x10 0.2120, 10x6 0.2241, 7x9 0.2115, 9x7 0.2180; steps per window 16 / 20 / 24 / 32:
+                    // 0.2110 / 0.2113 / 0.2120 / 0.2119; X = 8: 0.2255 -- the cube stays
+#define VX_LDS_DY VX_LDS_D
+#endif
+#ifndef VX_LDS_DZ
+#define VX_LDS_DZ VX_LDS_D
+#endif
+  static constexpr int Y = PHONG ? VX_LDS_DP : VX_LDS_DY;
+  static constexpr int Z = PHONG ? VX_LDS_DP : VX_LDS_DZ;
   static constexpr int RS = (X % 8 == 4) ? X : X + 4;             // row stride in words, = 4 mod 8
   static constexpr int SS = (Y * RS + 31 - 28) / 32 * 32 + 28;    // slice stride in words: >= Y * RS, = 28 mod 32
   static constexpr int ROWS = Y * Z;
