@@ -1258,8 +1258,9 @@ static int ensure_pipes(VxContext* c, int n) {
   VX_HIP(c, hipMemsetAsync(c->pipe_dc_pool, 0, ns * waves * sizeof(DevCounters), c->stream));   // ordered with the launches
   for (size_t i = 0; i < ns; ++i) {
     auto& p = c->pipes[i];
-    // streams only for the rolling-window path (<= 8 slots); the multi-frame kernel needs none
-    if (i < 8 && !p.stream) VX_HIP(c, hipStreamCreateWithFlags(&p.stream, hipStreamNonBlocking));
+    // streams only for the rolling-window path of the depth-parallel experiment (<= 8 slots); the multi-frame kernels
+    // need none
+    if (i < 8 && !p.stream && c->dp_active()) VX_HIP(c, hipStreamCreateWithFlags(&p.stream, hipStreamNonBlocking));
     if (!p.done) VX_HIP(c, hipEventCreateWithFlags(&p.done, hipEventDisableTiming));
     if (!p.merged) VX_HIP(c, hipEventCreateWithFlags(&p.merged, hipEventDisableTiming));
     p.has_merged = false;
