@@ -1137,6 +1137,21 @@ static int prepare_render(VxContext* c, dim3& grid) {
   c->dv.env_w = c->env_w;
   c->dv.env_h = c->env_h;
   {
+    // the wave-uniform terms of the primary ray (DevVolume::cam_o ...), with the operations of setup_world_ray /
+    // to_index (vx_device.hpp): fma chains in the same order, IEEE divisions -- the same bits as on the device
+    const VxParams& p = c->params;
+    auto mat4 = [](const float* m, float x, float y, float z, float w, float out[4]) {
+      for (int i = 0; i < 4; ++i) out[i] = fmaf(m[12 + i], w, fmaf(m[8 + i], z, fmaf(m[4 + i], y, m[i] * x)));
+    };
+    float cw[4], a[4];
+    mat4(p.camera_view_inv, 0.0f, 0.0f, 0.0f, 1.0f, cw);
+    for (int i = 0; i < 3; ++i) c->dv.cam_o[i] = cw[i] / cw[3];
+    mat4(p.density_transform_inv, c->dv.cam_o[0], c->dv.cam_o[1], c->dv.cam_o[2], 1.0f, a);
+    for (int i = 0; i < 3; ++i) c->dv.cam_ipos[i] = a[i];
+    c->dv.inv_res[0] = 1.0f / (float)p.res[0];
+    c->dv.inv_res[1] = 1.0f / (float)p.res[1];
+  }
+  {
     const VxParams& p = c->params;
     bool dvr = p.render_mode == VX_MODE_DVR || p.render_mode == VX_MODE_DVR_PHONG;
     if (dvr && p.dvr_skip_empty && !p.debug_hits) {

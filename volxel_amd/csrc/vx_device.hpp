@@ -50,6 +50,13 @@ struct DevVolume {
   const float* env_imp;         // levels 0..9 of the 512^2 map back to back (imp_offset)
   const float4* env_impq;       // the same levels 0..8 as 2x2 sibling quads, one 16-byte load per level
   float env_avg_w;              // level 9 (the mean importance)
+  // wave-uniform terms of the primary ray, evaluated once per launch on the host with the device's own operations
+  // (IEEE fma chains and divisions: vx_api.hip derive_camera) instead of once per wave on the vector ALUs -- the
+  // reference hoists its matrix inverses the same way (quirk Q11).  Perspective camera only (an orthographic ray's
+  // origin is per pixel); read by the tuned DVR kernels through dvr_setup.
+  float cam_o[3];               // inverse(view) * (0,0,0,1), divided by w          (utils.glsl:25-27)
+  float cam_ipos[3];            // density_transform_inv * (cam_o, 1)               (to_index of the origin)
+  float inv_res[2];             // 1 / u_res
 };
 
 constexpr uint32_t IMP_DIM = 512, IMP_LEVELS = 10, IMP_FLOATS = 349525;
@@ -465,9 +472,10 @@ VXD bool ray_box_intersection(const Ray& r, const float* bmin, const float* bmax
 }
 
 // A9: setup_world_ray, fragment.frag:57-65 + utils.glsl:23-40, inverses hoisted (Q11)
-VXD Ray setup_world_ray(const VxParams& p, float tex_x, float tex_y, float rx, float ry) {
-  float x_off = fma_(rx, 2.0f, -1.0f) * (1.0f / (float)p.res[0]);
-  float y_off = fma_(ry, 2.0f, -1.0f) * (1.0f / (float)p.res[1]);
+// hv: the host-evaluated uniform terms (DevVolume::cam_o ...), or nullptr to evaluate them here -- the same bits
+VXD Ray setup_world_ray(const VxParams& p, float tex_x, float tex_y, float rx, float ry, const DevVolume* hv = nullptr) {
+  float x_off = fma_(rx, 2.0f, -1.0f) * (hv ? hv->inv_res[0] : 1.0f / (float)p.res[0]);
+  float y_off = fma_(ry, 2.0f, -1.0f) * (hv ? hv->inv_res[1] : 1.0f / (float)p.res[1]);
   float sx = tex_x + x_off, sy = tex_y + y_off;
   float cw[4], vp[4], wp[4];
   if (p.camera_ortho) {  // [build] parallel rays: near-plane point of the pixel, camera -z axis (wave uniform)
@@ -476,8 +484,13 @@ VXD Ray setup_world_ray(const VxParams& p, float tex_x, float tex_y, float rx, f
     mat4_mul(p.camera_view_inv, 0.0f, 0.0f, -1.0f, 0.0f, cw);
     return Ray{v3(wp[0] / wp[3], wp[1] / wp[3], wp[2] / wp[3]), normalize3(v3(cw[0], cw[1], cw[2]))};
   }
-  mat4_mul(p.camera_view_inv, 0.0f, 0.0f, 0.0f, 1.0f, cw);
-  V3 cam = v3(cw[0] / cw[3], cw[1] / cw[3], cw[2] / cw[3]);
+  V3 cam;
+  if (hv) {
+    cam = v3(hv->cam_o[0], hv->cam_o[1], hv->cam_o[2]);
+  } else {
+    mat4_mul(p.camera_view_inv, 0.0f, 0.0f, 0.0f, 1.0f, cw);
+    cam = v3(cw[0] / cw[3], cw[1] / cw[3], cw[2] / cw[3]);
+  }
   mat4_mul(p.camera_proj_inv, fma_(sx, 2.0f, -1.0f), fma_(sy, 2.0f, -1.0f), 0.0f, 1.0f, vp);
   float vx_ = vp[0] / vp[3], vy_ = vp[1] / vp[3], vz_ = vp[2] / vp[3];
   mat4_mul(p.camera_view_inv, vx_, vy_, vz_, 1.0f, wp);
@@ -485,12 +498,16 @@ VXD Ray setup_world_ray(const VxParams& p, float tex_x, float tex_y, float rx, f
   return Ray{cam, normalize3(sub3(world, cam))};
 }
 
-VXD void to_index(const VxParams& p, const Ray& r, V3& ipos, V3& idir) {
+VXD void to_index(const VxParams& p, const Ray& r, V3& ipos, V3& idir, const DevVolume* hv = nullptr) {
   float a[4], b[4];
-  mat4_mul(p.density_transform_inv, r.o.x, r.o.y, r.o.z, 1.0f, a);
   mat4_mul(p.density_transform_inv, r.d.x, r.d.y, r.d.z, 0.0f, b);
-  ipos = v3(a[0], a[1], a[2]);
   idir = v3(b[0], b[1], b[2]);
+  if (hv && !p.camera_ortho) {   // the perspective origin is the camera: transformed once on the host
+    ipos = v3(hv->cam_ipos[0], hv->cam_ipos[1], hv->cam_ipos[2]);
+  } else {
+    mat4_mul(p.density_transform_inv, r.o.x, r.o.y, r.o.z, 1.0f, a);
+    ipos = v3(a[0], a[1], a[2]);
+  }
 }
 
 // texture(u_envmap, uv): LINEAR on level 0, REPEAT in s, CLAMP_TO_EDGE in t (environment.ts:22-26);

@@ -23,7 +23,7 @@ struct DvrRay {
   bool hit;
 };
 
-VXD DvrRay dvr_setup(const VxParams& p, int px, int py, uint32_t frame) {
+VXD DvrRay dvr_setup(const VxParams& p, const DevVolume& v, int px, int py, uint32_t frame) {
   float tex_x = ((float)px + 0.5f) / (float)p.res[0];
   float tex_y = ((float)py + 0.5f) / (float)p.res[1];
   float jx = 0.5f, jy = 0.5f, off = 0.5f;
@@ -35,12 +35,12 @@ VXD DvrRay dvr_setup(const VxParams& p, int px, int py, uint32_t frame) {
     (void)rng(s);      // tau_target slot of raymarch.glsl:28
     off = rng(s);      // start jitter, raymarch.glsl:30
   }
-  Ray ray = setup_world_ray(p, tex_x, tex_y, jx, jy);
+  Ray ray = setup_world_ray(p, tex_x, tex_y, jx, jy, &v);
   DvrRay r;
   float near, far;
   V3 ipos, idir;
   r.hit = ray_box_intersection(ray, p.volume_aabb_min, p.volume_aabb_max, near, far);
-  to_index(p, ray, ipos, idir);
+  to_index(p, ray, ipos, idir, &v);
   r.dt = p.dvr_step_voxels / sqrtf(dot3(idir, idir));
   const float t0 = fma_(off, r.dt, near);
   const float x = (far - t0) / r.dt;
@@ -114,7 +114,7 @@ __global__ __launch_bounds__(256) void render_dvr_cq(const VxParams p, const Dev
   const bool in_image = wave_pixel(tm, lt, wt, lane, px, py, si);
 
   DvrRay r{};
-  if (in_image) r = dvr_setup(p, px, py, frame);
+  if (in_image) r = dvr_setup(p, v, px, py, frame);
   bool alive = in_image && r.hit;
   const uint32_t n_rays = (uint32_t)__builtin_popcountll(__ballot(alive));
 
@@ -332,7 +332,7 @@ __global__ __launch_bounds__(256) void render_dvr_dp(const VxParams p, const Dev
     }
   }
   DvrRay r{};
-  if (in_image) r = dvr_setup(p, px, py, frame);   // the 8 lanes of a ray compute the same setup
+  if (in_image) r = dvr_setup(p, v, px, py, frame);   // the 8 lanes of a ray compute the same setup
   bool ray_alive = in_image && r.hit;
   const uint32_t n_rays = (uint32_t)__builtin_popcountll(__ballot(ray_alive && j0));
 

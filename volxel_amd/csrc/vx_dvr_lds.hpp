@@ -178,7 +178,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(PHONG ? (SK
   const bool in_image = wave_pixel(tm, lt, wt, plane, px, py, si);
 
   DvrRay r{};
-  if (in_image) r = dvr_setup(p, px, py, my_frame);
+  if (in_image) r = dvr_setup(p, v, px, py, my_frame);
   const bool hit0 = in_image && r.hit;
   const uint32_t n_rays = (uint32_t)__builtin_popcountll(ballot(hit0));
   // samples the lane's ray still has: k = 0 .. nray - 1 (march contract, vx_dvr.hpp); a ray that terminates early
