@@ -358,7 +358,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(VX_W_EVENTS
           const float tex_x = ((float)px + 0.5f) / (float)p.res[0];
           const float tex_y = ((float)py + 0.5f) / (float)p.res[1];
           const float a0 = rng(s), a1 = rng(s), b0 = rng(s), b1 = rng(s);               // :146
-          const Ray ray = setup_world_ray(p, tex_x, tex_y, (a0 + b0) / 2.0f, (a1 + b1) / 2.0f);
+          const Ray ray = setup_world_ray(p, tex_x, tex_y, (a0 + b0) / 2.0f, (a1 + b1) / 2.0f, &v);
           sto(PF_LX, 0.f); sto(PF_LY, 0.f); sto(PF_LZ, 0.f);
           sto(PF_TX, 1.f); sto(PF_TY, 1.f); sto(PF_TZ, 1.f);
           sto(PF_OX, ray.o.x); sto(PF_OY, ray.o.y); sto(PF_OZ, ray.o.z);

@@ -432,7 +432,7 @@ struct Frame {
     float jx = (a0 + b0) / 2.0f, jy = (a1 + b1) / 2.0f;
     constexpr bool DVR = (MODE == VX_MODE_DVR || MODE == VX_MODE_DVR_PHONG);
     if (DVR && !p.dvr_jitter) { jx = 0.5f; jy = 0.5f; }
-    Ray ray = setup_world_ray(p, tex_x, tex_y, jx, jy);
+    Ray ray = setup_world_ray(p, tex_x, tex_y, jx, jy, &v);   // uniform terms from the host (DevVolume::cam_o)
     float4 r;
     if (p.debug_hits) {  // :147-153
       float near, far;

@@ -102,7 +102,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(VX_W_PATHS,
     float tex_x = ((float)px + 0.5f) / (float)p.res[0];
     float tex_y = ((float)py + 0.5f) / (float)p.res[1];
     float a0 = rng(s), a1 = rng(s), b0 = rng(s), b1 = rng(s);              // :146
-    ray = setup_world_ray(p, tex_x, tex_y, (a0 + b0) / 2.0f, (a1 + b1) / 2.0f);
+    ray = setup_world_ray(p, tex_x, tex_y, (a0 + b0) / 2.0f, (a1 + b1) / 2.0f, &v);
     float near, far;
     if (fr.slab(ray, near, far)) c.rays++;
   }
