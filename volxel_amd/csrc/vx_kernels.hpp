@@ -51,10 +51,18 @@ VXD bool wave_pixel(const TileMap& tm, uint32_t lt, uint32_t wt, uint32_t lane, 
   return (uint32_t)px < tm.W && (uint32_t)py < tm.H;
 }
 
+// sum over the 64 lanes of the wave, in every lane: a DPP scan inside the rows of 16 lanes, two row broadcasts, one
+// v_readlane (6 vector instructions; the __shfl_down form went through ds_bpermute: ~30 instructions and six LDS round
+// trips per sum).  Every launch of this library runs whole waves (256-thread workgroups, no lane returns early).
 VXD uint32_t wave_sum(uint32_t x) {
-#pragma unroll
-  for (int o = 32; o > 0; o >>= 1) x += __shfl_down(x, o, 64);
-  return x;
+  int v = (int)x;
+  v += __builtin_amdgcn_update_dpp(0, v, 0x111, 0xf, 0xf, false);   // row_shr:1
+  v += __builtin_amdgcn_update_dpp(0, v, 0x112, 0xf, 0xf, false);   // row_shr:2
+  v += __builtin_amdgcn_update_dpp(0, v, 0x114, 0xf, 0xf, false);   // row_shr:4
+  v += __builtin_amdgcn_update_dpp(0, v, 0x118, 0xf, 0xf, false);   // row_shr:8  -> lane 15 of each row = row sum
+  v += __builtin_amdgcn_update_dpp(0, v, 0x142, 0xa, 0xf, false);   // row_bcast:15 into rows 1 and 3
+  v += __builtin_amdgcn_update_dpp(0, v, 0x143, 0xc, 0xf, false);   // row_bcast:31 into rows 2 and 3
+  return (uint32_t)__builtin_amdgcn_readlane(v, 63);
 }
 
 // Work counters: one record per wave of the launch grid, owned by that wave and updated with a
