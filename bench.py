@@ -54,8 +54,9 @@ BYTES_PER_PIXEL_RESULT = 16.0   # RGBA32F result written by the render kernel (o
 BYTES_PER_PIXEL_BLEND = 32.0    # accumulator read + write by the blend (+32 B per pixel per frame
                                 # = this + nothing else when a frame is blended in the render kernel itself)
 DEFAULT_FRAMES_PER_LAUNCH = 32
-KERNEL = {None: "vx::render_dvr_lds<16>", 0: "vx::render_generic<3,0>", 1: "vx::render_dvr_cq<4>", 2: "vx::render_dvr_lds<16>"}
-LAYOUT = {None: "brickf32", 0: "reference", 1: "cellquad", 2: "brickf32"}   # None = VX_LAYOUT_AUTO: DVR marches brickf32
+KERNEL = {None: "vx::render_dvr_lds<16>", 0: "vx::render_generic<3,0>", 1: "vx::render_dvr_cq<4>", 2: "vx::render_dvr_lds<16>",
+          4: "vx::render_dvr_lds<16,false,false,true>"}
+LAYOUT = {None: "brickf32", 0: "reference", 1: "cellquad", 2: "brickf32", 4: "bricku8"}   # None = VX_LAYOUT_AUTO: DVR marches brickf32
 
 
 def build_scene(width, height, n_vox, rank, world, device):
@@ -255,7 +256,8 @@ def main():
     ap.add_argument("--volume", type=int, default=512)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--layout", type=int, default=None,
-                    help="0 reference, 1 cellquad (gather kernel), 2 brickf32 (LDS-window kernel); default: the library's "
+                    help="0 reference, 1 cellquad (gather kernel), 2 brickf32 (LDS-window kernel), 4 bricku8 (the same kernel, 8-bit bricks "
+                         "decoded while a window is staged); default: the library's "
                          "VX_LAYOUT_AUTO, which marches DVR on brickf32")
     ap.add_argument("--gather-every", type=int, default=64,
                     help="N>1: all_gather the framebuffer once per this many accumulation frames")
@@ -468,7 +470,7 @@ def main():
         valu_peak = N_SIMDS * NOMINAL_CLOCK_GHZ / VALU_CLK_PER_INST            # G wave64 instructions per second
         valu_achieved = need / avg_kernel_s / 1e9 if avg_kernel_s > 0 else 0.0
         roof = {
-            "bound": "valu" if a.layout in (None, 2) else ("l1" if a.layout == 1 else "latency"),
+            "bound": "valu" if a.layout in (None, 2, 4) else ("l1" if a.layout == 1 else "latency"),
             "achieved": round(valu_achieved, 1), "peak": round(valu_peak, 1), "unit": "G wave64 VALU instructions/s",
             "frac": round(valu_achieved / valu_peak, 4),
             "frac_note": "necessary vector instructions (hand-derived minimum of the bit-exact march: 35 per sample and lane + 13 "
@@ -568,7 +570,7 @@ def main():
             # (2) the limiter the counters name
             if a.layout == 1:
                 roof["l1"] = l1_block(r, c)       # the cellquad gather kernel: vector L1 tag pipe
-            elif a.layout in (None, 2):
+            elif a.layout in (None, 2, 4):
                 roof["issue"] = issue_block(r, c, prof_entry)   # the LDS-window kernel: vector-ALU issue
         if world == 1 and not a.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(r, msg)

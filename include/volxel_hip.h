@@ -53,10 +53,16 @@ enum VxLayout {
   VX_LAYOUT_BRICKF32 = 2,  /* MI355X native: 8^3 bricks decoded to fp32, 2 KiB contiguous each (4 bytes
                               per voxel); the DVR / Phong kernel stages the window of voxels a wave is
                               marching through into LDS and takes every tap from there           */
-  VX_LAYOUT_AUTO = 3       /* default: each render mode on the layout its kernels are fastest on -- DVR and
+  VX_LAYOUT_AUTO = 3,      /* default: each render mode on the layout its kernels are fastest on -- DVR and
                               DVR + Phong on BRICKF32 (built at upload), the path-traced reference modes on
                               CELLQUAD (built the first time such a mode is rendered); volumes beyond the index
                               range of a layout fall back to REFERENCE for the modes concerned       */
+  VX_LAYOUT_BRICKU8 = 4    /* MI355X native, opt-in: the 8^3 bricks of BRICKF32 kept as the atlas' 8-bit codes
+                              (1 byte per voxel, 512 B per brick) + {min, max - min} per brick; the DVR / Phong
+                              kernel decodes them with A4's own fma while it stages a window into LDS -- the same
+                              bits as BRICKF32 at a quarter of the memory, a few per cent slower (the march is
+                              bound by the vector ALUs, not by HBM).  The path-traced modes sample the
+                              reference textures under this layout.                                     */
 };
 
 /*

@@ -58,7 +58,7 @@ def test_unorm_table():
     assert "gfx950" in name and cus == 256
 
 
-@pytest.mark.parametrize("layout", [0, 1, 2])
+@pytest.mark.parametrize("layout", [0, 1, 2, 4])
 @pytest.mark.parametrize("name", ["sphere32_debughits", "sphere32_dvr", "noise32_dvr_clip",
                                   "noise32_dvr_jitter_f3", "noise32_phong", "noise32_phong_jitter_f2",
                                   "sphere32_dvr_ortho", "noise32_dvr_ortho_jitter_f1"])
@@ -85,7 +85,7 @@ def test_golden_deterministic(oracle, name, layout):
         assert np.array_equal(img[box], want["image"][box])
 
 
-@pytest.mark.parametrize("layout", [1, 2])
+@pytest.mark.parametrize("layout", [1, 2, 4])
 def test_dvr_tuned_kernel_equals_generic(oracle, layout):
     """the tuned kernels (cellquad gather, brickf32 LDS tile) and the generic kernel are the
     same function"""
@@ -107,7 +107,36 @@ def test_dvr_tuned_kernel_equals_generic(oracle, layout):
     assert np.abs(a - b).max() <= 2e-6
 
 
-@pytest.mark.parametrize("layout", [0, 1, 2])
+@pytest.mark.parametrize("mode", ["dvr", "dvr_phong"])
+def test_bricku8_equals_brickf32_bit_for_bit(oracle, mode):
+    """VX_LAYOUT_BRICKU8 keeps the atlas codes and decodes them while a window is staged (vx_dvr_lds.hpp, U8): the values
+    that reach LDS are brickf32's, so accumulated images and every counter are identical -- multi-frame launches with
+    jitter, with and without exact empty-space skipping, on a volume with constant and out-of-atlas bricks"""
+    from tests.common import make_scene, benchmark_tf, BENCH_CAM
+    from volxel_amd import synth
+    inner, sp = synth.value_noise(64, seed=11, zero_quantile=0.5)
+    vox = np.zeros((96, 72, 88), dtype=np.uint16)            # extents that are not multiples of 8: padded bricks
+    vox[10:74, 4:68, 12:76] = inner
+    g = oracle.BrickGrid(vox, sp)
+    tf, L = benchmark_tf()
+    res = {}
+    for layout in (2, 4):
+        for skip in (0, 1):
+            s, cam, vol, ds, p = make_scene(g, 200, 136, mode, dvr_jitter=True, dvr_skip_empty=bool(skip),
+                                            sample_range=(0.05645751953125, 1.0), **BENCH_CAM)
+            r = _renderer(g, tf, L, p, layout)
+            r.settings = s; r.camera = cam
+            r.reset_counters()
+            r.render(frames=21, in_flight=8)                    # 2 single frames (launch order) + 8 + 8 + 3
+            c = r.counters()
+            res[(layout, skip)] = (r.read_accum(), c.samples, c.rays, c.tf_samples, c.grad_samples, c.lane_slots)
+    for skip in (0, 1):
+        a, b = res[(2, skip)], res[(4, skip)]
+        assert np.array_equal(a[0], b[0]), (mode, skip)
+        assert a[1:] == b[1:], (mode, skip, a[1:], b[1:])
+
+
+@pytest.mark.parametrize("layout", [0, 1, 2, 4])
 @pytest.mark.parametrize("name", ["noise32_raymarch", "noise32_no_dda", "noise32_default",
                                   "noise32_default_b3"])
 def test_golden_stochastic_modes(oracle, name, layout):
@@ -259,7 +288,7 @@ def test_golden_environment_deterministic(oracle, name):
     grid, tf, L, p, frame = build_case(oracle, name)
     assert p.use_env == 1
     want = np.load(os.path.join(GOLD, name + ".npz"))
-    for layout in (0, 1, 2):
+    for layout in (0, 1, 2, 4):
         r = _renderer(grid, tf, L, p, layout)
         r.reset_counters()
         img = _render_with_params(r, p, frame)
@@ -328,7 +357,7 @@ def test_config1_sphere_256_live_oracle(oracle):
     for mode, kw in (("dvr", {}), ("dvr", dict(debug_hits=True))):
         s, cam, vol, ds, p = make_scene(g, 256, 256, mode, **kw)
         want, oc = oracle.render(p, g, tf, L)
-        for layout in (0, 1, 2):
+        for layout in (0, 1, 2, 4):
             r = _renderer(g, tf, L, p, layout)
             img = _render_with_params(r, p)
             c = r.counters()
@@ -348,7 +377,7 @@ def test_config1_sphere_256_ortho_live_oracle(oracle):
         s, cam, vol, ds, p = make_scene(g, 256, 256, "dvr", ortho=0.6, **kw)
         assert p.camera_ortho == 1
         want, oc = oracle.render(p, g, tf, L, frame_index=frame)
-        for layout in (0, 1, 2):
+        for layout in (0, 1, 2, 4):
             r = _renderer(g, tf, L, p, layout)
             img = _render_with_params(r, p, frame=frame)
             c = r.counters()
@@ -499,7 +528,7 @@ def test_derived_tables_follow_their_inputs(oracle, mode):
     kept.close()
 
 
-@pytest.mark.parametrize("layout", [0, 1, 2])
+@pytest.mark.parametrize("layout", [0, 1, 2, 4])
 def test_empty_space_skipping_is_exact(oracle, layout):
     """skipping on/off: identical pixels, sample counts equal to the oracle's in both settings"""
     from tests.common import make_scene, benchmark_tf, BENCH_CAM
@@ -735,7 +764,7 @@ def test_edge_cases_match_oracle(oracle, case):
     kw.setdefault("sample_range", (0.05, 1.0))
     s, cam, vol, ds, p = make_scene(g, w, h, "dvr", **kw)
     want, oc = oracle.render(p, g, tf, L)
-    for layout in (0, 1, 2):
+    for layout in (0, 1, 2, 4):
         r = _renderer(g, tf, L, p, layout)
         r.reset_counters()
         img = _render_with_params(r, p)
@@ -1128,7 +1157,7 @@ def test_config5_1024_cubed_4k_eight_tile_shards(huge_scene, oracle):
     # the default layout marches through LDS windows of the 4.3 GB brickf32 layout; the cellquad gather kernel
     # (19.8 GB build, 24-bit brick index arithmetic) and the generic kernel on the reference textures (every tap
     # through range -> pointer -> atlas) evaluate the same samples: same count, image within the exp tolerance
-    for layout in (1, 0):
+    for layout in (1, 0, 4):
         r.set_layout(layout); r.restart_rendering(); r.reset_counters(); r.render(frames=3, in_flight=1)
         ref = r.read_accum(); c1 = r.counters()
         assert c1.samples == c0.samples and c1.rays == c0.rays, layout

@@ -44,6 +44,8 @@ struct VxContext {
   std::vector<void*> vol_allocs;
   void* cq_alloc = nullptr;
   void* bf_alloc = nullptr;
+  void* bu_alloc = nullptr;    // bricku8 codes (+ one zero unit)
+  void* bur_alloc = nullptr;   // bricku8 per-brick {min, max - min} (+ the {0, 0} entry of the zero unit)
   int layout = VX_LAYOUT_AUTO;       // what the host asked for (vx_set_layout); eff_layout() is what a launch samples
   bool auto_no_cq = false;           // AUTO: the volume is too large for the cellquad layout (path modes use REFERENCE)
   bool auto_no_bf = false;           // AUTO: too large for brickf32 as well (everything uses REFERENCE)
@@ -159,8 +161,11 @@ static void free_volume(VxContext* c) {
   c->vol_allocs.clear();
   if (c->cq_alloc) (void)hipFree(c->cq_alloc);
   if (c->bf_alloc) (void)hipFree(c->bf_alloc);
+  if (c->bu_alloc) (void)hipFree(c->bu_alloc);
+  if (c->bur_alloc) (void)hipFree(c->bur_alloc);
   c->cq_alloc = nullptr;
   c->bf_alloc = nullptr;
+  c->bu_alloc = c->bur_alloc = nullptr;
   c->dv = DevVolume{};
   c->has_volume = false;
   c->skip_dirty = true;
@@ -664,6 +669,11 @@ static int alloc_layout(VxContext* c, uint32_t& n_layers) {
     c->dv.bf = nullptr;
     c->dv.bf_zero = 0;
   }
+  if (c->bu_alloc) (void)hipFree(c->bu_alloc);
+  if (c->bur_alloc) (void)hipFree(c->bur_alloc);
+  c->bu_alloc = c->bur_alloc = nullptr;
+  c->dv.bu = nullptr;
+  c->dv.bu_range = nullptr;
   n_layers = 0;
   c->auto_no_cq = c->auto_no_bf = false;
   if (c->layout == VX_LAYOUT_AUTO) {   // what the volume's size allows
@@ -684,6 +694,22 @@ static int alloc_layout(VxContext* c, uint32_t& n_layers) {
     VX_HIP(c, hipMemsetAsync((char*)c->bf_alloc + n_vox * sizeof(float), 0, 16, c->stream));
     c->dv.bf = (const float*)c->bf_alloc;
     c->dv.bf_zero = n_vox <= 0xfffffff0ull ? (uint32_t)n_vox : 0u;
+    n_layers = c->dv.bc[2];
+    return VX_OK;
+  }
+  if (primary_layout(c) == VX_LAYOUT_BRICKU8) {
+    const uint64_t n_bricks = (uint64_t)c->dv.bc[0] * c->dv.bc[1] * c->dv.bc[2];
+    const uint64_t n_units = n_bricks * 128u;   // dwords of four codes; the staging indexes them with 32 bits
+    if (n_units > 0xfffffff0ull)
+      VX_FAIL(c, VX_ERR_INVALID, "volume too large for the bricku8 layout (%llu bricks): select VX_LAYOUT_REFERENCE "
+              "with vx_set_layout", (unsigned long long)n_bricks);
+    // + one zero unit behind the last brick and its {0, 0} range: rows and chunks outside the volume decode to +0
+    VX_HIP(c, hipMalloc(&c->bu_alloc, (n_units + 4u) * sizeof(uint32_t)));
+    VX_HIP(c, hipMalloc(&c->bur_alloc, (n_bricks + 1u) * sizeof(float2)));
+    VX_HIP(c, hipMemsetAsync((char*)c->bu_alloc + n_units * sizeof(uint32_t), 0, 4u * sizeof(uint32_t), c->stream));
+    VX_HIP(c, hipMemsetAsync((char*)c->bur_alloc + n_bricks * sizeof(float2), 0, sizeof(float2), c->stream));
+    c->dv.bu = (const uint32_t*)c->bu_alloc;
+    c->dv.bu_range = (const float2*)c->bur_alloc;
     n_layers = c->dv.bc[2];
     return VX_OK;
   }
@@ -713,6 +739,14 @@ static int build_layout_layers(VxContext* c, uint32_t z0, uint32_t z1, hipStream
                          (float*)c->bf_alloc, at, at + n);
       at += n;
     }
+  } else if (primary_layout(c) == VX_LAYOUT_BRICKU8) {
+    const uint64_t bricks_per = (uint64_t)c->dv.bc[0] * c->dv.bc[1];
+    const uint64_t first = bricks_per * 128u * z0, end = bricks_per * 128u * z1;   // dword units, < 2^32 (alloc_layout)
+    hipLaunchKernelGGL(build_bricku8, dim3((uint32_t)((end - first + 255) / 256)), dim3(256), 0, st, c->dv,
+                       (uint32_t*)c->bu_alloc, first, end);
+    const uint32_t b0 = (uint32_t)(bricks_per * z0), b1 = (uint32_t)(bricks_per * z1);
+    hipLaunchKernelGGL(build_bricku8_range, dim3((b1 - b0 + 255) / 256), dim3(256), 0, st, c->dv, (float2*)c->bur_alloc,
+                       b0, b1);
   } else if (primary_layout(c) == VX_LAYOUT_CELLQUAD) {
     const uint64_t per = (uint64_t)c->dv.cq_bc[0] * c->dv.cq_bc[1] * CQ_BRICK_QUADS;
     const uint64_t first = per * z0, end = per * z1;
@@ -972,7 +1006,7 @@ int vx_set_layout(VxContext* c, int layout) {
   if (!c) return VX_ERR_INVALID;
   VX_DEV(c);
   if (layout != VX_LAYOUT_REFERENCE && layout != VX_LAYOUT_CELLQUAD && layout != VX_LAYOUT_BRICKF32 &&
-      layout != VX_LAYOUT_AUTO)
+      layout != VX_LAYOUT_AUTO && layout != VX_LAYOUT_BRICKU8)
     VX_FAIL(c, VX_ERR_INVALID, "vx_set_layout: unknown layout %d", layout);
   if (layout == c->layout) return VX_OK;
   c->layout = layout;
@@ -1113,6 +1147,8 @@ static bool tuned_possible(const VxContext* c) {
 // the LDS-window kernel (vx_dvr_lds.hpp): DVR on the brickf32 layout, Phong wherever brickf32 data is resident
 static bool use_lds_kernel(const VxContext* c) {
   if (!tuned_possible(c)) return false;
+  if (eff_layout(c) == VX_LAYOUT_BRICKU8)   // the same kernel, staging from the 8-bit bricks
+    return (c->params.render_mode == VX_MODE_DVR || c->params.render_mode == VX_MODE_DVR_PHONG) && c->dv.bu != nullptr;
   if (c->params.render_mode == VX_MODE_DVR) return eff_layout(c) == VX_LAYOUT_BRICKF32;
   return c->params.render_mode == VX_MODE_DVR_PHONG && c->dv.bf != nullptr;
 }
@@ -1136,6 +1172,7 @@ static int prepare_render(VxContext* c, dim3& grid) {
   c->dv.env_avg_w = c->env_avg_w;
   c->dv.env_w = c->env_w;
   c->dv.env_h = c->env_h;
+  c->dv.bu_active = (eff_layout(c) == VX_LAYOUT_BRICKU8 && c->dv.bu) ? 1u : 0u;
   {
     // the wave-uniform terms of the primary ray (DevVolume::cam_o ...), with the operations of setup_world_ray /
     // to_index (vx_device.hpp): fma chains in the same order, IEEE divisions -- the same bits as on the device

@@ -35,6 +35,13 @@ struct DevVolume {
   // MI355X layout "brickf32": every 8^3 brick decoded to fp32, 2 KiB contiguous, brick-major
   const float* bf;              // [bc.z][bc.y][bc.x][8][8][8], one all-zero 16-byte chunk behind the last brick
   uint32_t bf_zero;             // index (in floats) of that chunk, or 0 when the layout needs more than 32 index bits
+  // MI355X layout "bricku8" (opt-in): the same bricks as the atlas' 8-bit codes, 4 per dword, dword index = the
+  // 16-byte-unit index of brickf32 (brick * 128 + z * 16 + y * 2 + (x >> 2)); one zero dword behind the last brick.
+  // bu_range[b] = {min, max - min} of brick b (range texture, decoded from f16); the entry behind the last brick is
+  // {0, 0}: it serves the zero dword, so rows and chunks outside the volume decode to 0 (A4).
+  const uint32_t* bu;
+  const float2* bu_range;
+  uint32_t bu_active;           // this launch samples bricku8 (set by vx_api prepare_render)
   // exact empty-space skipping (DVR): one bit per macro cell of 8 << skip_level voxels
   const uint32_t* skip_bits;    // nullptr: none
   uint32_t skip_level;
@@ -255,6 +262,29 @@ VXD float lookup_density_brick(const DevVolume& v, int x, int y, int z) {
   un = inz ? un : 0.0f;
   const float r = fma_(un, mx - mn, mn);
   return in ? r : 0.0f;
+}
+
+// the 8-bit code lookup_density_brick decodes for an in-extent voxel (0 where the robust fetch returns 0: unorm8(0) == 0),
+// for the bricku8 build
+VXD uint32_t lookup_code_brick(const DevVolume& v, uint32_t ux, uint32_t uy, uint32_t uz) {
+  const uint32_t bi = ((uz >> 3) * v.bc[1] + (uy >> 3)) * v.bc[0] + (ux >> 3);
+  const uint32_t ptr = v.indirection[bi];
+  const uint32_t ax = ((ptr & 1023u) << 3) + (ux & 7u);
+  const uint32_t ay = (((ptr >> 10) & 1023u) << 3) + (uy & 7u);
+  const uint32_t az = (((ptr >> 20) & 1023u) << 3) + (uz & 7u);
+  const bool inz = az < v.atlas_size[2];
+  const size_t ao = ((size_t)az * v.atlas_size[1] + ay) * v.atlas_size[0] + ax;
+  const uint32_t code = v.atlas[inz ? ao : (size_t)0];
+  return inz ? code : 0u;
+}
+// four codes of one dword -> densities: A4's decode, fma(unorm8(code), max - min, min)
+VXD float4 decode_codes4(uint32_t code4, float2 rg) {
+  float4 r;
+  r.x = fma_(unorm8(code4 & 255u), rg.y, rg.x);
+  r.y = fma_(unorm8((code4 >> 8) & 255u), rg.y, rg.x);
+  r.z = fma_(unorm8((code4 >> 16) & 255u), rg.y, rg.x);
+  r.w = fma_(unorm8(code4 >> 24), rg.y, rg.x);
+  return r;
 }
 
 VXD float gl_mix(float x, float y, float a) { return fma_(y, a, x * (1.0f - a)); }

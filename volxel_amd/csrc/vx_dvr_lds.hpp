@@ -136,7 +136,10 @@ VXD float mix8(float v000, float v100, float v010, float v110, float v001, float
 #endif
 typedef const float __attribute__((address_space(3))) * LdsFloatPtr;
 
-template <int S, bool PHONG, bool SKIP>
+// U8: the window is staged from the bricku8 layout (8-bit codes + a range per brick, decoded here with A4's fma) instead
+// of brickf32's fp32 voxels -- the dword index of a 4-voxel chunk is brickf32's 16-byte-unit index, so the row and chunk
+// arithmetic is shared; everything after the staging is the same code on the same values.
+template <int S, bool PHONG, bool SKIP, bool U8 = false>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(PHONG ? (SKIP ? 1 : VX_W_LDS_PHONG) : (SKIP ? VX_W_LDS_SKIP : VX_W_LDS), 8))) void render_dvr_lds(const VxParams p, const DevVolume v,
                                                        const float4* __restrict__ tf_global, uint32_t tf_len,
                                                        const MultiOut mo, float weight, const TileMap tm,
@@ -196,6 +199,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(PHONG ? (SK
   const uint32_t ex = v.extent[0], ey = v.extent[1], ez = v.extent[2];
   const uint32_t bcx = v.bc[0], bcy = v.bc[1];
   const float4* __restrict__ bf4 = reinterpret_cast<const float4*>(v.bf);   // 16-byte units: 64 GiB of layout in 32 bits
+  const uint32_t* __restrict__ bu = v.bu;                                   // U8: one dword of four codes per unit
+  const float2* __restrict__ bur = v.bu_range;
   const uint32_t zero_chunk = bcx * bcy * v.bc[2] * 128u;   // the all-zero chunk behind the last brick (vx_api alloc_layout)
   const uint32_t sh = 3u + v.skip_level, md0 = v.skip_dims[0], md1 = v.skip_dims[1];
   const uint32_t cmaxx = ex + 7u, cmaxy = ey + 7u, cmaxz = ez + 7u;
@@ -343,11 +348,31 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(PHONG ? (SK
       // selected away, whatever their index came to.)
       const uint32_t rowbase = (mad24(mad24((uint32_t)gz >> 3, bcy, (uint32_t)gy >> 3) & 0xffffffu, bcx, 0u) << 7) +
                                ((((uint32_t)gz & 7u) << 4) | (((uint32_t)gy & 7u) << 1));
+      if (U8) {
+        // codes and brick ranges of the row's chunks first (all loads in flight), then the decode; the unit behind the
+        // last brick is a zero dword under the range {0, 0}: fma(0, 0, 0) = +0, as A4 asks for outside the volume
+        uint32_t code[NC];
+        float2 rg[NC];
 #pragma unroll
-      for (int c = 0; c < NC; ++c) {
-        const uint32_t at = (rin && xin[c]) ? rowbase + xoff[c] : zero_chunk;
-        const float4 val = bf4[at];
-        vals[ps][c] = val;
+        for (int c = 0; c < NC; ++c) {
+          const uint32_t at = (rin && xin[c]) ? rowbase + xoff[c] : zero_chunk;
+          const uint32_t cw = bu[at];
+          const float2 rr = bur[at >> 7];
+          code[c] = cw;
+          rg[c] = rr;
+        }
+#pragma unroll
+        for (int c = 0; c < NC; ++c) {
+          const float4 val = decode_codes4(code[c], rg[c]);
+          vals[ps][c] = val;
+        }
+      } else {
+#pragma unroll
+        for (int c = 0; c < NC; ++c) {
+          const uint32_t at = (rin && xin[c]) ? rowbase + xoff[c] : zero_chunk;
+          const float4 val = bf4[at];
+          vals[ps][c] = val;
+        }
       }
     }
     n_loads += (uint32_t)NC * (uint32_t)TL::PASSES;
@@ -636,13 +661,16 @@ inline void launch_dvr_lds(const VxParams& p, const DevVolume& v, const float4* 
   const bool phong = p.render_mode == VX_MODE_DVR_PHONG;
   const size_t tile_bytes = 4u * (size_t)(phong ? LdsTile<true>::FLOATS : LdsTile<false>::FLOATS) * sizeof(float);
   const size_t lds = (size_t)tf_len * sizeof(float4) + (skip ? (((size_t)v.skip_words + 3u) & ~(size_t)3u) * 4u : 0u) + tile_bytes;
-#define VX_LAUNCH_LDS(PH, SK) \
-  hipLaunchKernelGGL((render_dvr_lds<(PH ? VX_LDS_S_PHONG : VX_LDS_S), PH, SK>), grid, block, lds, stream, p, v, tf, tf_len, mo, \
-                     weight, tm, order)
+#define VX_LAUNCH_LDS(PH, SK, U)                                                                                          \
+  hipLaunchKernelGGL((render_dvr_lds<(PH ? VX_LDS_S_PHONG : VX_LDS_S), PH, SK, U>), grid, block, lds, stream, p, v, tf, tf_len, \
+                     mo, weight, tm, order)
+  const bool u8 = v.bu_active != 0u;
   if (phong) {
-    if (skip) VX_LAUNCH_LDS(true, true); else VX_LAUNCH_LDS(true, false);
+    if (skip) { if (u8) VX_LAUNCH_LDS(true, true, true); else VX_LAUNCH_LDS(true, true, false); }
+    else      { if (u8) VX_LAUNCH_LDS(true, false, true); else VX_LAUNCH_LDS(true, false, false); }
   } else {
-    if (skip) VX_LAUNCH_LDS(false, true); else VX_LAUNCH_LDS(false, false);
+    if (skip) { if (u8) VX_LAUNCH_LDS(false, true, true); else VX_LAUNCH_LDS(false, true, false); }
+    else      { if (u8) VX_LAUNCH_LDS(false, false, true); else VX_LAUNCH_LDS(false, false, false); }
   }
 #undef VX_LAUNCH_LDS
 }

@@ -406,6 +406,31 @@ __global__ __launch_bounds__(256) void build_brickf32(const DevVolume v, float* 
                                 (int)(bz * 8u + (l >> 6)));
 }
 
+// reference layout -> bricku8: one thread per dword (4 voxels along x) of the padded grid, and one per brick range
+__global__ __launch_bounds__(256) void build_bricku8(const DevVolume v, uint32_t* __restrict__ out, uint64_t first,
+                                                      uint64_t end) {
+  uint64_t i = first + (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;   // dword index
+  if (i >= end) return;
+  uint32_t l = (uint32_t)(i & 127u);        // z * 16 + y * 2 + (x >> 2)
+  uint64_t b = i >> 7;
+  uint32_t bx = (uint32_t)(b % v.bc[0]);
+  uint32_t by = (uint32_t)((b / v.bc[0]) % v.bc[1]);
+  uint32_t bz = (uint32_t)(b / ((uint64_t)v.bc[0] * v.bc[1]));
+  const uint32_t x0 = bx * 8u + (l & 1u) * 4u, y = by * 8u + ((l >> 1) & 7u), z = bz * 8u + (l >> 4);
+  uint32_t w = 0u;
+#pragma unroll
+  for (uint32_t j = 0; j < 4u; ++j) w |= lookup_code_brick(v, x0 + j, y, z) << (8u * j);
+  out[i] = w;
+}
+__global__ __launch_bounds__(256) void build_bricku8_range(const DevVolume v, float2* __restrict__ out, uint32_t first,
+                                                            uint32_t end) {
+  uint32_t b = first + blockIdx.x * blockDim.x + threadIdx.x;
+  if (b >= end) return;
+  const uint32_t rg = v.range[b];
+  const float mn = half_bits_to_float(rg >> 16), mx = half_bits_to_float(rg & 0xffffu);
+  out[b] = make_float2(mn, mx - mn);   // lookup_density_brick: fma(un, mx - mn, mn)
+}
+
 // ---- ordered running-mean blend of pipelined frame results (fragment.frag:158 applied n times) ----
 struct MergeArgs {
   const float4* result[MERGE_MAX];

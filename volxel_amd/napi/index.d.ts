@@ -26,7 +26,7 @@ export declare class Environment {          // representation/environment.ts; ro
   static default(): Environment;
 }
 export declare class Volxel3DDicomRenderer {
-  /** layout: 0 reference textures, 1 cellquad, 2 brickf32, 3 (default) per render mode -- include/volxel_hip.h VxLayout */
+  /** layout: 0 reference textures, 1 cellquad, 2 brickf32, 3 (default) per render mode, 4 bricku8 (8-bit bricks decoded at staging) -- include/volxel_hip.h VxLayout */
   constructor(opts?: { width?: number; height?: number; device?: number; layout?: number; lowResPreview?: boolean });
   environment: Environment | null;
   setEnvironment(env: Environment | null): void;
