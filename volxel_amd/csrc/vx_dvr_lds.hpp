@@ -122,7 +122,7 @@ VXD float mix8(float v000, float v100, float v010, float v110, float v001, float
   return fma_(h, fz, l * wz);
 }
 
-// occupancy asked of the register allocator: the DVR build fits 58 VGPRs without a spill and gains from 8 resident
+// occupancy asked of the register allocator: the DVR build fits 61 VGPRs without a scratch access and gains from 8 resident
 // waves per SIMD (ms per frame at 5 / 6 / 7 / 8 waves: 0.434 / 0.431 / 0.420 / 0.415); the Phong build needs 86
 #ifndef VX_W_LDS
 #define VX_W_LDS 8
