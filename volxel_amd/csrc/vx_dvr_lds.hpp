@@ -375,7 +375,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(PHONG ? (SK
         }
       }
     }
-    n_loads += (uint32_t)NC * (uint32_t)TL::PASSES;
+    n_loads += (U8 ? 2u : 1u) * (uint32_t)NC * (uint32_t)TL::PASSES;   // U8: a dword of codes and a brick range per chunk
   };
   // stage, part 2: the rows into the wave's tile
   auto write_tile = [&](float4 (&vals)[TL::PASSES][NC]) {
