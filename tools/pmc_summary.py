@@ -56,12 +56,15 @@ if line and by:
     n_timed = int(line["roofline"]["launches"])
     fps = int(line["config"].get("frames_per_step", 1))
     n_warm = -(-max(int(line["warmup"]) * fps, 2) // fpl)
-    first = n_warm + ((n_warm + n_timed) if line.get("value_cold") else 0)
+    # the first warm-up call of a fresh context renders its first two frames one by one (they build the launch order)
+    # and the rest of its frames in a smaller launch: one launch fewer of the full size
+    n_warm_full = max(n_warm - 1, 0) if fpl > 2 else n_warm
+    first = n_warm_full + ((n_warm + n_timed) if line.get("value_cold") else 0)
     tv = v[first:first + n_timed] if len(v) >= first + n_timed else v
     print("\n## the timed launches")
     print(f"The --stats average above mixes every launch of the kernel: the warm-up steps (the first one runs on a chip at")
     print(f"its idle clocks), other frames per launch, the single-frame side measurement.  In launch order the {len(v)} launches of")
-    print(f"{fpl} frames = grid {gt} are {n_warm} warm-up + {n_timed} timed + the rest; the {len(tv)} timed ones: kernel trace mean "
+    print(f"{fpl} frames = grid {gt} are {n_warm_full} warm-up + {n_timed} timed + the rest; the {len(tv)} timed ones: kernel trace mean "
           f"{sum(tv)/len(tv):.4f} ms (min {min(tv):.4f}, max {max(tv):.4f}); bench.py (HIP events, same run) "
           f"roofline.avg_kernel_ms {line['roofline']['avg_kernel_ms']}")
     by[gt] = tv
