@@ -243,6 +243,20 @@ def workload_name(a, world):
     return "custom"
 
 
+def launch_plan(first, count, per_launch, gather_every):
+    """`count` accumulation frames first.. as equal launches of at most `per_launch` frames (20 frames at 16 per launch go
+    as 10 + 10); a launch is followed by the exchange step when its last frame completes a group of `gather_every`
+    frames (display cadence).  Returns [(first frame, frames, exchange afterwards)] -- tests/test_bench_plan.py."""
+    plan, done = [], 0
+    while done < count:
+        launches_left = -(-(count - done) // per_launch)
+        n = -(-(count - done) // launches_left)
+        f0 = first + done
+        plan.append((f0, n, (f0 + n) // gather_every != f0 // gather_every))
+        done += n
+    return plan
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -334,14 +348,13 @@ def main():
     F = max(1, a.frames_per_step)
     frames_timed, frames_warm = a.steps * F, max(a.warmup * F, 2)
 
-    def batch(f0, n, per_launch):
+    def batch(f0, n, per_launch, exchange):
         """n accumulation frames f0.. (n <= per_launch): one launch, then -- at display cadence -- the gather"""
         if state["copy_done"] is not None:        # the snapshot copy must have read the slab
             rs.wait_event(state["copy_done"])
             state["copy_done"] = None
         r.render(frames=n, rebind=False, in_flight=per_launch)
-        f = f0 + n - 1
-        if use_dist and (f + 1) // a.gather_every != f0 // a.gather_every:
+        if use_dist and exchange:
             gather()
 
     def gather():
@@ -373,14 +386,11 @@ def main():
             sys.stderr.write("fence: " + " ".join(f"{(b - a) * 1e3:.3f}" for a, b in zip(tt, tt[1:])) + " ms\n")
 
     def run(first, count, need_image=False, per_launch=P):
-        done, before = 0, state["gathers"]
-        while done < count:                   # equal launches: 20 frames at 16 per launch go as 10 + 10
-            launches_left = -(-(count - done) // per_launch)
-            n = -(-(count - done) // launches_left)
-            batch(first + done, n, per_launch)
-            done += n
-        if need_image and use_dist and state["gathers"] == before:
-            gather()                          # a timed run always delivers at least one gathered image
+        plan = launch_plan(first, count, per_launch, a.gather_every)
+        for f0, n, exchange in plan:
+            batch(f0, n, per_launch, exchange)
+        if need_image and use_dist and plan and not plan[-1][2]:
+            gather()                          # a timed run delivers the image of ALL its frames
 
     if use_dist:
         # RCCL's first barrier sets the collective up (12 ms measured): here, not in the fence before the timed region,
