@@ -2,8 +2,8 @@
 """bench.py -- headline benchmark: Gsamples/s of the DVR raymarch on BASELINE config 3
 (512^3 volume, 1920x1080, trilinear + 1-D TF LUT, early ray termination, clip box).
 
-    python bench.py --gpus 1 --steps K --warmup W
-    python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
+    python bench.py --gpus N --steps K --warmup W        (N > 1 with no launcher around it: starts its own N ranks, launch_ranks)
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...      (the driver's form)
 
 A "step" is one batch of `--frames-per-step` (32) accumulation frames of the 1080p image -- the unit the host hands
 the device (`Volxel3DRenderer.render(frames)` batches 32 frames per launch; the viewer accumulates up to 2000,
@@ -257,6 +257,29 @@ def launch_plan(first, count, per_launch, gather_every):
     return plan
 
 
+def launch_ranks(n, argv):
+    """`python bench.py --gpus N` without a launcher around it: start the N ranks the way the driver does
+    (`python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P bench.py ...`)
+    as a CHILD process and return its exit code.  Rank 0's JSON line reaches stdout through the inherited descriptor.
+    If the ranks cannot start or any of them fails the code is non-zero: there is no fall-back to fewer ranks."""
+    import socket
+    import subprocess
+    with socket.socket() as s:                 # a free rendezvous port on the loopback interface
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n}",
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__), *argv]
+    sys.stderr.write(f"bench.py: launching {n} ranks: {' '.join(cmd)}\n")
+    sys.stderr.flush()
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")     # dmabuf IPC: the only mode the host driver supports (RCCL)
+    try:
+        return subprocess.run(cmd, env=env).returncode or 0
+    except OSError as e:
+        sys.stderr.write(f"bench.py: could not start the ranks: {e}\n")
+        return 1
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -297,6 +320,11 @@ def main():
                     help="N>1: keep the default round-robin dealing of the 64x64 tiles instead of the cost-balanced order")
     a = ap.parse_args()
 
+    if a.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        # `python bench.py --gpus N` on its own: this process becomes the launcher of N ranks and never touches the GPU
+        # (no torch import, no HIP call before or after the spawn; a child process, never an exec)
+        raise SystemExit(launch_ranks(a.gpus, sys.argv[1:]))
+
     # the contract is ONE JSON line on stdout: keep a private handle to the real stdout and send
     # everything else written to fd 1 (RCCL prints a version banner there) to stderr
     sys.stdout.flush()
@@ -309,10 +337,13 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
-    if world != a.gpus and world > 1:
+    if world != a.gpus:
+        # never report a run of `world` ranks as one of `--gpus` GPUs
         raise SystemExit(f"--gpus {a.gpus} but WORLD_SIZE={world}")
     if not torch.cuda.is_available():
-        raise SystemExit("bench.py needs an MI355X: the HIP path has no CPU fallback")
+        raise SystemExit(f"bench.py needs an MI355X: the HIP path has no CPU fallback (rank {rank} of {world})")
+    if torch.cuda.device_count() < (local + 1):
+        raise SystemExit(f"rank {rank} of {world}: no GPU {local} on this node ({torch.cuda.device_count()} visible)")
     torch.cuda.set_device(local)
     use_dist = world > 1 or a.force_gather
     if use_dist:

@@ -44,3 +44,29 @@ def test_plan_edges():
     assert b.launch_plan(0, 0, 32, 64) == []
     p = b.launch_plan(3, 1000, 64, 64)
     assert sum(n for _, n, _ in p) == 1000 and all(n <= 64 for _, n, _ in p)
+
+
+def test_gpus_n_launches_its_own_ranks():
+    """`python bench.py --gpus 2` with no launcher around it starts two ranks as child processes (the parent never touches
+    the GPU).  Here there is no GPU: the ranks must reach the no-GPU exit with RANK / WORLD_SIZE set, the whole command
+    must fail, and nothing may be printed on stdout -- never a 1-rank result reported for a 2-GPU command."""
+    import subprocess
+    import sys
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "0"],
+                       env=env, capture_output=True, text=True, timeout=300)
+    assert p.returncode != 0
+    assert p.stdout.strip() == ""
+    assert "launching 2 ranks" in p.stderr
+    ranks = {int(m) for m in __import__("re").findall(r"needs an MI355X.*\(rank (\d) of 2\)", p.stderr)}
+    assert ranks and ranks <= {0, 1}          # torchrun may end the second rank as soon as the first one fails
+
+
+def test_world_size_must_match_gpus():
+    """a launcher that sets WORLD_SIZE to something other than --gpus is refused, not silently accepted"""
+    import subprocess
+    import sys
+    env = dict(os.environ, WORLD_SIZE="1", RANK="0", LOCAL_RANK="0")
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "8"], env=env, capture_output=True,
+                       text=True, timeout=300)
+    assert p.returncode != 0 and "WORLD_SIZE=1" in p.stderr and p.stdout.strip() == ""
