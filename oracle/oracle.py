@@ -120,16 +120,45 @@ def build(force=False):
 
 
 _lib = None
+_variants = {}
+VARIANTS = ("contract", "nocontract", "ulp2")
+
+
+class variant:
+    """`with oracle.variant("nocontract"): ...` -- route every oracle call inside the block through one of the
+    tolerance-envelope builds of the same source (oracle/Makefile): "nocontract" rounds every a*b+c twice, "ulp2" biases
+    the transcendental built-ins by 2 ulps; "contract" is the arithmetic contract itself (the default library)."""
+
+    def __init__(self, name):
+        assert name in VARIANTS, name
+        self.name = name
+
+    def __enter__(self):
+        global _lib
+        self.prev = _lib
+        _lib = _load({"contract": None, "nocontract": "libvx_oracle_nocontract.so", "ulp2": "libvx_oracle_ulp2.so"}[self.name])
+        return _lib
+
+    def __exit__(self, *exc):
+        global _lib
+        _lib = self.prev
 
 
 def lib():
     global _lib
-    if _lib is not None:
-        return _lib
-    name = "libvx_oracle.so" if _has_fma() else "libvx_oracle_nofma.so"
+    if _lib is None:
+        _lib = _load(None)
+    return _lib
+
+
+def _load(name):
+    if name is None:
+        name = "libvx_oracle.so" if _has_fma() else "libvx_oracle_nofma.so"
+    if name in _variants:
+        return _variants[name]
     path = os.path.join(_HERE, "_build", name)
     if not os.path.exists(path):
-        build()
+        build(force=True)
     L = C.CDLL(path)
     u32, f32, vp, i32 = C.c_uint32, C.c_float, C.c_void_p, C.c_int32
     P = C.POINTER
@@ -173,7 +202,12 @@ def lib():
     L.vxo_skip_level.argtypes = [P(VxoVolume)]; L.vxo_skip_level.restype = C.c_int
     L.vxo_skip_dims.argtypes = [P(VxoVolume), C.c_int, P(u32)]
     L.vxo_build_skip_mask.argtypes = [P(VxParams), P(VxoVolume), vp, u32, C.c_int, vp]
-    _lib = L
+    L.vxo_render_ray_samples.argtypes = [P(VxParams), u32, P(VxoVolume), vp, u32, P(VxoEnvironment), vp, vp, i32, i32, i32,
+                                         i32, P(VxoCounters)]
+    L.vxo_render_ray_samples.restype = C.c_int
+    L.vxo_set_dvr_march.argtypes = [C.c_int]
+    L.vxo_get_dvr_march.restype = C.c_int
+    _variants[name] = L
     return L
 
 
@@ -273,9 +307,26 @@ def copy_params(src) -> VxParams:
     return dst
 
 
+class dvr_march:
+    """`with oracle.dvr_march(walk_t=True): ...` -- render DVR with the march contract of rounds 1-2 (vx_oracle.h
+    vxo_set_dvr_march); the shipped contract is restored on exit"""
+
+    def __init__(self, walk_t):
+        self.walk_t = int(bool(walk_t))
+
+    def __enter__(self):
+        self.L = lib()
+        self.prev = self.L.vxo_get_dvr_march()
+        self.L.vxo_set_dvr_march(self.walk_t)
+
+    def __exit__(self, *exc):
+        self.L.vxo_set_dvr_march(self.prev)
+
+
 def render(params, grid, tf, tf_len, frame_index=0, sample_weight=0.0, prev=None, rect=None,
-           threads=None, env=None):
-    """fragment.frag main over the image (or rect = (x0,x1,y0,y1)); returns (rgba, counters)."""
+           threads=None, env=None, ray_samples=False):
+    """fragment.frag main over the image (or rect = (x0,x1,y0,y1)); returns (rgba, counters) -- with ray_samples=True
+    (rgba, counters, uint32 (H, W) samples evaluated per pixel)."""
     L = lib()
     p = copy_params(params)
     W, H = p.res[0], p.res[1]
@@ -289,8 +340,16 @@ def render(params, grid, tf, tf_len, frame_index=0, sample_weight=0.0, prev=None
     bands = np.linspace(y0, y1, min(threads * 4, max(y1 - y0, 1)) + 1).astype(int)
     totals = VxoCounters()
 
+    per_ray = np.zeros((H, W), dtype=np.uint32) if ray_samples else None
+
     def work(i):
         c = VxoCounters()
+        if ray_samples:
+            rc = L.vxo_render_ray_samples(C.byref(p), frame_index, C.byref(vol), tf.ctypes.data, tf_len,
+                                          C.byref(env.c) if env is not None else None, out.ctypes.data,
+                                          per_ray.ctypes.data, x0, x1, int(bands[i]), int(bands[i + 1]), C.byref(c))
+            assert rc == 0, rc
+            return c
         rc = L.vxo_render_env(C.byref(p), frame_index, sample_weight, C.byref(vol), tf.ctypes.data,
                               tf_len, C.byref(env.c) if env is not None else None,
                               prev.ctypes.data if prev is not None else None, out.ctypes.data,
@@ -306,6 +365,8 @@ def render(params, grid, tf, tf_len, frame_index=0, sample_weight=0.0, prev=None
     for c in cs:
         for f, _ in VxoCounters._fields_:
             setattr(totals, f, getattr(totals, f) + getattr(c, f))
+    if ray_samples:
+        return out, totals, per_ray
     return out, totals
 
 

@@ -26,6 +26,29 @@
 #include <stdlib.h>
 #include <string.h>
 
+/* ---- tolerance-envelope variants (oracle/Makefile; tests/test_tolerance_envelope.py) -----------------------------------
+ * GLSL ES 3.00 leaves two things to the implementation that the arithmetic contract above FIXES: whether a*b+c is contracted
+ * into one rounding, and how many ulps the transcendental built-ins may be off.  No WebGL2 implementation can run here, so the
+ * nearest thing to "how far is the reference's own output from this oracle" is how far the ORACLE moves when those two
+ * freedoms are exercised the other way.  The contract build defines neither macro and is bit-for-bit what it was.
+ *   VXO_NO_CONTRACTION        every a*b+c the contract fuses is rounded twice (an implementation that never contracts)
+ *   VXO_TRANSCENDENTAL_ULPS=n exp / log / pow / sin / cos / atan / acos results are biased by n ulps (relative n * 2^-23):
+ *                             an implementation at the far end of a n-ulp error budget, every call off in the same direction */
+#ifdef VXO_NO_CONTRACTION
+static inline float vxo_unfused(float a, float b, float c) { const float prod = a * b; return prod + c; }
+#define fmaf(a, b, c) vxo_unfused((a), (b), (c))
+#endif
+#ifdef VXO_TRANSCENDENTAL_ULPS
+static inline float vxo_biased(float r) { return r * (1.0f + (float)(VXO_TRANSCENDENTAL_ULPS) * 1.1920929e-7f); }
+#define expf(x) vxo_biased(expf(x))
+#define logf(x) vxo_biased(logf(x))
+#define powf(x, y) vxo_biased(powf((x), (y)))
+#define sinf(x) vxo_biased(sinf(x))
+#define cosf(x) vxo_biased(cosf(x))
+#define atan2f(y, x) vxo_biased(atan2f((y), (x)))
+#define acosf(x) vxo_biased(acosf(x))
+#endif
+
 /* ------------------------------------------------------------------------------------ */
 /* small helpers of the arithmetic contract                                              */
 
@@ -1113,6 +1136,14 @@ static inline int cell_is_skipped(const Ctx* k, int32_t c0, int32_t c1, int32_t 
 /* SURVEY.md section 8 row A12 / Appendix A.5.  Loop body restates raymarch.glsl:38-52
  * with lookup_density_trilinear (common.glsl:61-69) in place of the stochastic tap and the
  * early-out on accumulated optical depth.                                               */
+/* The march contract of rounds 1-2, kept as a second path: t_k = fma(k, dt, t0), a sample exists while
+ * t_k < far (and k < max_steps), its position is fma(t_k, idir, ipos) and the cell frame of A5 is that minus 1/2.  The same
+ * line, walked with one more rounding per axis; vxo_set_dvr_march(1) selects it.  tests/test_tolerance_envelope.py pins
+ * the shipped contract against it: per-ray sample counts within +-1, images within the stated tolerance. */
+static int g_dvr_walk_t = 0;
+void vxo_set_dvr_march(int walk_t) { g_dvr_walk_t = walk_t; }
+int vxo_get_dvr_march(void) { return g_dvr_walk_t; }
+
 static void dvr_pixel(Ctx* k, Ray ray, float start_offset, int phong, float out[4]) {
   const VxParams* p = k->p;
   float near, far;
@@ -1138,8 +1169,17 @@ static void dvr_pixel(Ctx* k, Ray ray, float start_offset, int phong, float out[
     v3 nl = V3(-p->light_dir[0], -p->light_dir[1], -p->light_dir[2]);
     v3 hv = V3(0, 0, 0);
     if (phong) hv = normalize3(sub3(nl, ray.d)); /* Blinn half vector of l and v = -dir */
-    for (; kf < nf; kf += 1.0f) {
-      const float qx = fmaf(kf, dq.x, q0.x), qy = fmaf(kf, dq.y, q0.y), qz = fmaf(kf, dq.z, q0.z);
+    const int walk_t = g_dvr_walk_t;
+    const float n_steps = walk_t ? (float)p->dvr_max_steps : nf;
+    for (; kf < n_steps; kf += 1.0f) {
+      float qx, qy, qz;
+      if (walk_t) {                                  /* the rounds 1-2 contract */
+        const float t = fmaf(kf, dt, t0);
+        if (!(t < far)) break;
+        qx = fmaf(t, idir.x, ipos.x) - 0.5f; qy = fmaf(t, idir.y, ipos.y) - 0.5f; qz = fmaf(t, idir.z, ipos.z) - 0.5f;
+      } else {
+        qx = fmaf(kf, dq.x, q0.x); qy = fmaf(kf, dq.y, q0.y); qz = fmaf(kf, dq.z, q0.z);
+      }
       const float flx = floorf(qx), fly = floorf(qy), flz = floorf(qz);
       const float fx = qx - flx, fy = qy - fly, fz = qz - flz;
       const int32_t cx = f2i(flx), cy = f2i(fly), cz = f2i(flz);
@@ -1284,9 +1324,30 @@ int vxo_render(const VxParams* p, uint32_t frame_index, float sample_weight, con
   return vxo_render_env(p, frame_index, sample_weight, v, tf, tf_len, NULL, prev, out, x0, x1, y0, y1, counters);
 }
 
+static int render_rect(const VxParams* p, uint32_t frame_index, float sample_weight, const VxoVolume* v,
+                       const float* tf, uint32_t tf_len, const VxoEnvironment* env, const float* prev,
+                       float* out, uint32_t* ray_samples, int32_t x0, int32_t x1, int32_t y0, int32_t y1,
+                       VxoCounters* counters);
+
 int vxo_render_env(const VxParams* p, uint32_t frame_index, float sample_weight, const VxoVolume* v,
                    const float* tf, uint32_t tf_len, const VxoEnvironment* env, const float* prev,
                    float* out, int32_t x0, int32_t x1, int32_t y0, int32_t y1, VxoCounters* counters) {
+  return render_rect(p, frame_index, sample_weight, v, tf, tf_len, env, prev, out, NULL, x0, x1, y0, y1, counters);
+}
+
+/* the same, and the number of samples every pixel's paths evaluated (samples + skipped steps) into
+   ray_samples[py * res.x + px] -- for tests that compare march contracts ray by ray */
+int vxo_render_ray_samples(const VxParams* p, uint32_t frame_index, const VxoVolume* v, const float* tf,
+                           uint32_t tf_len, const VxoEnvironment* env, float* out, uint32_t* ray_samples,
+                           int32_t x0, int32_t x1, int32_t y0, int32_t y1, VxoCounters* counters) {
+  if (!ray_samples) return 1;
+  return render_rect(p, frame_index, 0.0f, v, tf, tf_len, env, NULL, out, ray_samples, x0, x1, y0, y1, counters);
+}
+
+static int render_rect(const VxParams* p, uint32_t frame_index, float sample_weight, const VxoVolume* v,
+                       const float* tf, uint32_t tf_len, const VxoEnvironment* env, const float* prev,
+                       float* out, uint32_t* ray_samples, int32_t x0, int32_t x1, int32_t y0, int32_t y1,
+                       VxoCounters* counters) {
   if (!p || !v || !tf || !out || tf_len == 0) return 1;
   if (p->use_env > 0 && !env) return 2;
   Ctx k;
@@ -1307,7 +1368,9 @@ int vxo_render_env(const VxParams* p, uint32_t frame_index, float sample_weight,
   for (int32_t py = y0; py < y1; ++py)
     for (int32_t px = x0; px < x1; ++px) {
       float r[4];
+      const uint64_t before = k.c.samples + k.c.skip_steps;
       shade_pixel(&k, px, py, r, NULL);
+      if (ray_samples) ray_samples[(size_t)py * W + px] = (uint32_t)(k.c.samples + k.c.skip_steps - before);
       size_t o = ((size_t)py * W + px) * 4;
       /* :158 out = (w*prev + (1-w)*result).rgb, alpha 1 */
       for (int c = 0; c < 3; ++c) {

@@ -114,6 +114,18 @@ int vxo_render_env(const VxParams* p, uint32_t frame_index, float sample_weight,
                    const float* tf, uint32_t tf_len, const VxoEnvironment* env, const float* prev,
                    float* out, int32_t x0, int32_t x1, int32_t y0, int32_t y1, VxoCounters* counters);
 
+/* the same with per-pixel sample counts (samples + skipped steps of the pixel's paths) into
+ * ray_samples[py * res.x + px]; sample_weight 0 */
+int vxo_render_ray_samples(const VxParams* p, uint32_t frame_index, const VxoVolume* v, const float* tf,
+                           uint32_t tf_len, const VxoEnvironment* env, float* out, uint32_t* ray_samples,
+                           int32_t x0, int32_t x1, int32_t y0, int32_t y1, VxoCounters* counters);
+
+/* [build] DVR march contract: 0 = shipped (n = ceil((far - t0) / dt) samples at q = fma(k, dq, q0)), 1 = the contract of
+ * rounds 1-2 (t_k = fma(k, dt, t0) while t_k < far, position fma(t_k, idir, ipos) - 1/2).  Process-wide switch, set
+ * between renders; tests/test_tolerance_envelope.py pins one against the other. */
+void vxo_set_dvr_march(int walk_t);
+int vxo_get_dvr_march(void);
+
 /* ---- full fragment program (shaders/fragment.frag main) over a pixel rectangle ----
  * out / prev: res.x*res.y*4 floats, row 0 = bottom.  Only pixels in [x0,x1) x [y0,y1) are
  * written.  prev may be NULL when sample_weight == 0. */

@@ -224,7 +224,7 @@ def test_repacked_path_kernel_is_bit_identical(oracle, mode, bounces, monkeypatc
     g = oracle.BrickGrid(vox, sp)
     tf, L = benchmark_tf()
     res = {}
-    for kern in ("generic", "packed", "events"):     # "events": the shipped default (vx_events.hpp) for default / no_dda
+    for kern in ("generic", "packed", "events"):     # "generic" ships; "packed" (vx_paths.hpp) and "events" (vx_events.hpp) are opt-in
         monkeypatch.setenv("VX_PATHS_KERNEL", kern)
         for layout in (0, 1, 2):
             r = Volxel3DRenderer(200, 136, layout=layout)       # not a multiple of 16: partial workgroups
@@ -997,6 +997,61 @@ def test_fullsize_config3_config4_match_live_oracle(big_scene, oracle, mode):
         r.settings.render_mode, r.settings.dvr_jitter, r.settings.dvr_skip_empty = old
 
 
+def _check_reference_mode_frame(r, msg, oracle, mode, frame, rect=None, launch_frames=8):
+    """one accumulation frame of a reference render mode (dda.glsl:65-98 `default`, normal.glsl:33-57 `no_dda`,
+    raymarch.glsl:25-55 `raymarch`, each under fragment.frag:79-124) at the scene's full size against the live oracle:
+    through vx_render_frame (one pixel per lane) and as the LAST frame of a `launch_frames`-frame vx_render_frames launch
+    (lanes = pixels x frames).  The small goldens' criteria: >= 99.9 % of the pixels within 1e-4 (a 1-ulp
+    log() can flip one collision decision and re-roll that pixel), samples and DDA steps within 0.2 %, rays counted
+    exactly as the oracle's when no decision flipped (within 0.2 % otherwise)."""
+    W, H = r.width, r.height
+    old = (r.settings.render_mode, r.settings.bounces)
+    r.settings.render_mode = mode
+    try:
+        p = r.bind_uniforms()
+        r.restart_rendering(); r.reset_counters()
+        r._check(r._lib.vx_render_frame(r._ctx, frame, 0.0))
+        img = r.read_accum(); c = r.counters()
+        assert c.pixels == W * H and np.isfinite(img).all()
+        # the same frame as the last of a multi-frame launch (weights 0: the accumulator keeps the last frame)
+        r.restart_rendering(); r.reset_counters()
+        w = (C.c_float * launch_frames)(*([0.0] * launch_frames))
+        r._check(r._lib.vx_render_frames(r._ctx, frame - launch_frames + 1, launch_frames, w, launch_frames))
+        img_n = r.read_accum(); cn = r.counters()
+        assert cn.max_launch_frames == launch_frames and cn.launches == 1
+        assert np.array_equal(img_n, img), mode            # HIP against HIP: bit for bit
+        x0, x1, y0, y1 = rect if rect else (0, W, 0, H)
+        want, oc = oracle.render(p, oracle.make_volume(msg), *r._tf, frame_index=frame, rect=(x0, x1, y0, y1),
+                                 threads=16, env=_oracle_env(oracle, r))
+        diff = np.abs(img[y0:y1, x0:x1] - want[y0:y1, x0:x1]).max(axis=2)
+        frac = float((diff <= 1e-4).mean())
+        print(f"full size {mode}: {frac * 100:.4f} % of {diff.size} pixels within 1e-4, {int((diff > 1e-4).sum())} re-rolled, "
+              f"oracle samples {oc.samples} rays {oc.rays} steps {oc.skip_steps}")
+        assert frac >= 0.999, (mode, frac, float(diff.max()))
+        if rect is None:
+            assert abs(int(c.samples) - int(oc.samples)) <= 0.002 * oc.samples + 64, (c.samples, oc.samples)
+            assert abs(int(c.skip_steps) - int(oc.skip_steps)) <= 0.002 * oc.skip_steps + 64, (c.skip_steps, oc.skip_steps)
+            assert abs(int(c.rays) - int(oc.rays)) <= 0.002 * oc.rays + 64, (c.rays, oc.rays)
+            if mode == "default":
+                assert oc.skip_steps > oc.samples > 1e6       # the DDA really walks at this size
+            else:
+                assert oc.samples > 1e7
+        return frac
+    finally:
+        r.settings.render_mode, r.settings.bounces = old
+        r.bind_uniforms()
+
+
+@pytest.mark.parametrize("mode", ["default", "no_dda", "raymarch"])
+def test_fullsize_reference_modes_match_live_oracle(big_scene, oracle, mode):
+    """the reference's own three render modes on the BASELINE config-3 scene -- 512^3, 1920x1080, clip box, the benchmark's
+    transfer function and camera -- on the AUTO layout (the 2.5 GB cellquad build and its 24-bit brick index arithmetic for
+    the trilinear modes, the majorant tables of the DDA), the whole 1080p frame against the oracle."""
+    r, msg = big_scene
+    r.set_layout(3)
+    _check_reference_mode_frame(r, msg, oracle, mode, frame=9)
+
+
 def test_fullsize_config2_ct_phantom_matches_live_oracle(oracle):
     """BASELINE config 2 at its full size: a 256^3 CT stack as 256 DICOM slices (explicit VR little endian, 12 bits
     stored) through the native DICOM reader and brick builder, 1920x1080, trilinear + 1-D transfer function, jitter on;
@@ -1202,6 +1257,17 @@ def test_config5_1024_cubed_4k_eight_tile_shards(huge_scene, oracle):
     mean = sum(per_rank) / N
     assert max(abs(x - mean) for x in per_rank) / mean < 0.03
     rr.close()
+
+
+@pytest.mark.parametrize("mode", ["default", "no_dda", "raymarch"])
+def test_config5_reference_modes_crop_matches_live_oracle(huge_scene, oracle, mode):
+    """the reference's modes on the 1024^3 volume at 3840x2160 (AUTO layout: 19.8 GB of cell quads, 128^3 bricks, three
+    majorant mips): the centred 960x540 crop of one frame against the oracle -- the crop bounds the oracle's time, the
+    device renders the whole 4K frame, alone and as the last of a 4-frame launch"""
+    r, msg = huge_scene
+    r.set_layout(3)
+    x0, y0 = (3840 - 960) // 2, (2160 - 540) // 2
+    _check_reference_mode_frame(r, msg, oracle, mode, frame=6, rect=(x0, x0 + 960, y0, y0 + 540), launch_frames=4)
 
 
 def test_volume_beyond_the_cellquad_index_range_is_refused(oracle):

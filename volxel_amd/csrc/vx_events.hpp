@@ -31,7 +31,7 @@
 //     environment warp, trigonometry): batched, it runs for 16+ lanes per pass instead of 1-2.
 // Every path carries its own xoshiro state and consumes exactly the draws of fragment.frag:79-124 in their order, so
 // pixels, sample counts and DDA step counts are bit-identical to render_generic -- hence to the oracle -- whichever
-// lane runs them and in whatever order (tests/test_gpu_parity.py::test_event_kernel_is_bit_identical).
+// lane runs them and in whatever order (tests/test_gpu_parity.py::test_repacked_path_kernel_is_bit_identical, kernel "events").
 // Per-path state that only events touch (radiance, throughput, world ray, pixel) lives in LDS, one dword per lane
 // and field: 88 bytes per lane.
 #pragma once
