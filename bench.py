@@ -233,6 +233,42 @@ def issue_block(r, c, entry):
     return out
 
 
+MODE_BYTES_PER_SAMPLE = {"default": 16.0, "no_dda": 16.0, "raymarch": 9.0, "dvr": 16.0, "dvr_phong": 64.0}
+
+
+def mode_record(mode, c, a):
+    """one render mode on the bench scene: kernel time per accumulation frame, its rate, and the SURVEY 8(d) byte roofline
+    (bytes per sample by the taps the mode fetches + 4 B per DDA step + 32 B per pixel and frame, over the kernel time and
+    the HBM peak).  Lane utilisation comes from the committed PMC profile of this launch shape, when there is one."""
+    frames = max(int(c.frames), 1)
+    ms = c.kernel_ms / frames
+    alg = (c.samples * MODE_BYTES_PER_SAMPLE[mode] + c.skip_steps * 4.0 + c.pixels * BYTES_PER_PIXEL_BLEND) / frames
+    gbs = alg / (ms * 1e-3) / 1e9 if ms > 0 else 0.0
+    rec = {"ms_per_frame": round(ms, 4),
+           "samples_per_frame": int(c.samples // frames),
+           "dda_steps_per_frame": int(c.skip_steps // frames),
+           "rays_per_frame": int(c.rays // frames),
+           "gsamples_per_s": round(c.samples / (c.kernel_ms * 1e-3) / 1e9, 2) if c.kernel_ms else None,
+           "frames_per_launch": int(c.max_launch_frames),
+           "roofline": {"bound": "hbm", "unit": "GB/s", "model": "algorithmic bytes (SURVEY 8(d))",
+                        "bytes_per_sample": MODE_BYTES_PER_SAMPLE[mode], "algorithmic_bytes_per_frame": int(alg),
+                        "achieved": round(gbs, 1), "peak": HBM_PEAK_GBS, "frac": round(gbs / HBM_PEAK_GBS, 4)},
+           "lane_utilisation": (round(c.samples / c.lane_slots, 4) if c.lane_slots else None),
+           "lane_utilisation_source": "counted by the kernel (samples / lane slots)" if c.lane_slots else None}
+    try:
+        prof = json.load(open(os.path.join(ROOT, "profiles", "modes.json")))
+        e = prof.get(mode)
+        if e and (e["width"], e["height"], e["volume"]) == (a.width, a.height, a.volume) and rec["lane_utilisation"] is None:
+            rec["lane_utilisation"] = e["lane_utilisation"]
+            rec["lane_utilisation_source"] = e["source"]
+            for k in ("hbm_bytes_per_frame", "l1_hit", "l2_hit"):
+                if k in e:
+                    rec[k] = e[k]
+    except Exception:
+        pass
+    return rec
+
+
 def workload_name(a, world):
     """BASELINE.json `configs` index of the workload (configs[2] = config 3 is the one `metric` is quoted on)"""
     shape = (a.volume, a.width, a.height)
@@ -510,10 +546,22 @@ def main():
         need = (c.samples * NECESSARY_VALU["per_sample"] + c.tf_samples * NECESSARY_VALU["per_tf_sample"]) / 64.0 / launches
         valu_peak = N_SIMDS * NOMINAL_CLOCK_GHZ / VALU_CLK_PER_INST            # G wave64 instructions per second
         valu_achieved = need / avg_kernel_s / 1e9 if avg_kernel_s > 0 else 0.0
+        valu_bound = a.layout in (None, 2, 4)
+        issued = prof_entry.get("sq_insts_valu_per_launch") if prof_entry else None
         roof = {
-            "bound": "valu" if a.layout in (None, 2, 4) else ("l1" if a.layout == 1 else "latency"),
-            "achieved": round(valu_achieved, 1), "peak": round(valu_peak, 1), "unit": "G wave64 VALU instructions/s",
-            "frac": round(valu_achieved / valu_peak, 4),
+            "bound": "valu" if valu_bound else ("l1" if a.layout == 1 else "latency"),
+            # the VALU model only describes the kernel it was derived for: null for the gather / reference-layout kernels
+            # (--layout 1: see roofline.l1; --layout 0 has no single limiter)
+            "achieved": round(valu_achieved, 1) if valu_bound else None,
+            "peak": round(valu_peak, 1) if valu_bound else None, "unit": "G wave64 VALU instructions/s",
+            "frac": round(valu_achieved / valu_peak, 4) if valu_bound else None,
+            "frac_kind": "model x measurement: NECESSARY vector instructions per sample (a hand-derived count, checked against "
+                         "the kernel's ISA listing by tests/test_isa_lint.py) x the samples this run counted / the kernel time "
+                         "this run measured; `frac_issued` is the same ratio for the instructions the kernel actually ISSUED "
+                         "(rocprofv3 SQ_INSTS_VALU of this command, profiles/traffic.json), idle lanes and overhead included",
+            "frac_issued": (round(issued / avg_kernel_s / 1e9 / valu_peak, 4)
+                            if (valu_bound and issued and avg_kernel_s > 0) else None),
+            "necessary_over_issued": round(need / issued, 4) if (valu_bound and issued) else None,
             "frac_note": "necessary vector instructions (hand-derived minimum of the bit-exact march: 35 per sample and lane + 13 "
                          "per sample inside the sample range, / 64 lanes; per-ray set-up, window placement and idle lanes are "
                          "NOT counted as necessary) per launch / kernel time, against 1024 SIMDs x 2.4 GHz / 2 clocks per instruction",
@@ -640,10 +688,13 @@ def main():
                 r.render(frames=3, rebind=False); r.finish(); r.reset_counters()
                 r.render(frames=P, rebind=False, in_flight=P); r.finish()
                 cs_ = r.counters()
-                other[mode] = {"ms_per_frame": round(cs_.kernel_ms / cs_.frames, 4),
-                               "samples_per_frame": int(cs_.samples // cs_.frames),
-                               "frames_per_launch": int(cs_.max_launch_frames)}
+                other[mode] = mode_record(mode, cs_, a)
             out["config"]["other_modes"] = other
+            out["config"]["other_modes_note"] = (
+                "roofline = SURVEY 8(d) byte model / kernel time / 8000 GB/s: 16 B per trilinear sample (default, no_dda), 9 B "
+                "per nearest-tap sample (raymarch), 64 B per Phong-shaded DVR sample position (16 B x the sample and its gradient "
+                "taps' cells), 4 B per DDA step, 32 B per pixel and frame; lane_utilisation = SQ_ACTIVE_INST_VALU lanes / 64 of "
+                "the rocprofv3 PMC pass named in lane_utilisation_source (null when no profile of this build is committed)")
         real_stdout.write(json.dumps(out) + "\n")
         real_stdout.flush()
     if use_dist:
