@@ -252,7 +252,11 @@ def mode_record(mode, c, a):
            "frames_per_launch": int(c.max_launch_frames),
            "roofline": {"bound": "hbm", "unit": "GB/s", "model": "algorithmic bytes (SURVEY 8(d))",
                         "bytes_per_sample": MODE_BYTES_PER_SAMPLE[mode], "algorithmic_bytes_per_frame": int(alg),
-                        "achieved": round(gbs, 1), "peak": HBM_PEAK_GBS, "frac": round(gbs / HBM_PEAK_GBS, 4)},
+                        "achieved": round(gbs, 1), "peak": HBM_PEAK_GBS, "frac": round(gbs / HBM_PEAK_GBS, 4),
+                        **({"above_peak": "the byte model charges every tap to HBM; this kernel takes its taps from LDS windows "
+                                          "staged once (vx_dvr_lds.hpp), so the model exceeds what the HBM pins carry: "
+                                          "not a roofline fraction, see the top-level roofline for the limiter"}
+                           if gbs > HBM_PEAK_GBS else {})},
            "lane_utilisation": (round(c.samples / c.lane_slots, 4) if c.lane_slots else None),
            "lane_utilisation_source": "counted by the kernel (samples / lane slots)" if c.lane_slots else None}
     try:

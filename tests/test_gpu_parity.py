@@ -834,7 +834,18 @@ def test_error_contract():
         with pytest.raises(VolxelError, match=field):
             r.bind_uniforms()
         setattr(r.settings, field, good)
-    r.bind_uniforms()
+    p = r.bind_uniforms()
+    # a clip box that reaches beyond the volume's own box (the viewer never produces one, volume.ts:32-37) is refused
+    # at render time on every layout alike, instead of sampling clamped edge cells on one layout and zeros on the others
+    import copy
+    q = copy.copy(p)
+    q.volume_aabb_max[0] = p.volume_aabb_max[0] + 0.25
+    for layout in (0, 1, 2):
+        r.set_layout(layout)
+        r._check(r._lib.vx_set_params(r._ctx, C.byref(q)))
+        assert r._lib.vx_render_frame(r._ctx, 0, 0.0) == 1 and b"outside the volume" in r._lib.vx_last_error(r._ctx)
+    r._check(r._lib.vx_set_params(r._ctx, C.byref(p)))
+    r._check(r._lib.vx_render_frame(r._ctx, 0, 0.0))
 
 
 def test_host_rejects_arrays_shorter_than_their_size_fields(oracle):

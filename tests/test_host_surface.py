@@ -81,6 +81,9 @@ def test_zip_rules_follow_zip_rs():
         read_zip_slices(b"this is not a zip archive")
     with pytest.raises(ZipReadError, match="NoFiles: No dicom data collected"):
         read_zip_slices(_zip([("only/", b"")]))
+    assert read_zip_slices(_zip([("..foo.dcm", b"7")])) == [b"7"]      # a legal enclosed name that merely starts with dots
+    with pytest.raises(ZipReadError, match="ExtractFailed"):
+        read_zip_slices(_zip([("../escape.dcm", b"7")]))
 
 
 @pytest.mark.parametrize("rle", [False, True])
@@ -93,6 +96,18 @@ def test_radiance_environment_decode(rle):
         decode_environment(b"\x76\x2f\x31\x01" + b"\0" * 32)
     with pytest.raises(ValueError, match="unrecognised"):
         decode_environment(b"PNG....")
+    if rle:
+        # malformed run-length data is an error, never a hang or a read past the buffer (the image crate errors too)
+        head = b"#?RADIANCE\nFORMAT=32-bit_rle_rgbe\n\n-Y 1 +X 16\n" + bytes([2, 2, 0, 16])
+        for body in (bytes([0, 0, 0]),                 # zero-length literal: x would never advance
+                     bytes([128, 7]),                   # zero-length run
+                     bytes([128 + 17, 7]),              # run past the scanline
+                     bytes([16, 1, 2, 3]),              # literal past the end of the buffer
+                     bytes([128 + 16])):                # the run's value byte is missing
+            with pytest.raises(ValueError, match="Radiance map"):
+                decode_environment(head + body)
+        with pytest.raises(ValueError, match="ends early"):
+            decode_environment(data[:-3] if not rle else b"#?RADIANCE\nFORMAT=32-bit_rle_rgbe\n\n-Y 2 +X 4\n" + bytes(20))
 
 
 def _bare_renderer():

@@ -82,3 +82,29 @@ def test_built_library_listing_is_clean(native_lib):
     findings, stats = L.scan(listing)
     assert findings == []
     assert sum(1 for k in stats if "render_" in k) >= 20
+
+
+def test_necessary_instruction_model_matches_the_listing(native_lib):
+    """bench.py's roofline fraction multiplies a HAND-DERIVED count -- NECESSARY_VALU: 35 vector instructions per sample, 13
+    more per sample inside the sample range; NECESSARY_CLK: the same priced at the measured opcode rates -- by counted samples.
+    This ties the hand count to what the compiler actually emitted for the headline kernel's all-lanes march loop
+    (tools/isa_cost.py march_loop_counts on the listing that came out of the library's own compile): the loop may not be
+    cheaper than the "necessary" count claims (then the model would overstate the floor), and it should not be much dearer
+    (then the kernel left the floor and the fraction is stale)."""
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("bench_model", os.path.join(ROOT, "bench.py"))
+    b = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(b)
+    import isa_cost
+    listing = os.path.join(ROOT, "volxel_amd", "csrc", "vx_api.s")
+    if not os.path.exists(listing):
+        subprocess.check_call(["make", "-C", os.path.join(ROOT, "volxel_amd", "csrc"), "-s", "-B", "vx_api.o"])
+    m = isa_cost.march_loop_counts(listing)
+    need, clk = b.NECESSARY_VALU, b.NECESSARY_CLK
+    assert m["tap_reads"] == 4                                            # eight taps as four ds_read2_b32
+    assert need["per_sample"] <= m["per_step"] <= need["per_sample"] + 2, m
+    assert clk["per_sample"] <= m["per_step_clk"] <= clk["per_sample"] + 8, m
+    # the composite block also holds what the model does not call necessary: the upper range compare, the alpha select,
+    # the termination select and one register move
+    assert need["per_tf_sample"] <= m["per_tf_step"] <= need["per_tf_sample"] + 5, m
+    assert clk["per_tf_sample"] <= m["per_tf_step_clk"] <= clk["per_tf_sample"] + 16, m

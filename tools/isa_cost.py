@@ -31,6 +31,39 @@ def price(line):
     return base, 4
 
 
+def march_loop_counts(path, kernel="_ZN2vx14render_dvr_ldsILi16ELb0ELb0ELb0E"):
+    """the all-lanes march loop of the headline kernel in the listing: (vector instructions every wave step executes,
+    vector instructions of the block only wave steps with a sample inside the sample range execute, priced clocks of the
+    two).  The loop is the first block after the kernel's main loop header that holds the four ds_read2_b32 of a sample's
+    eight taps; the in-range block is the stretch its one forward s_cbranch_scc1 jumps over.  bench.py's NECESSARY_VALU /
+    NECESSARY_CLK are the hand-derived minima these counts are held against (tests/test_isa_lint.py)."""
+    lines = open(path).read().splitlines()
+    start = next(i for i, l in enumerate(lines) if l.startswith(kernel) and re.match(r"\w+:", l))   # the function's label
+    end = next(i for i in range(start, len(lines)) if "s_endpgm" in lines[i])
+    first = next(i for i in range(start, end) if "ds_read2_b32" in lines[i])
+    top = max(i for i in range(start, first) if re.match(r"\.LBB\d+_\d+:", lines[i]))
+    label = lines[top].split(":")[0]
+    back = next(i for i in range(first, end) if re.match(r"\s*s_c?branch(_\w+)?\s+" + re.escape(label) + r"\b", lines[i]))
+    skip = next(i for i in range(first, back) if re.match(r"\s*s_cbranch_scc1\s+\.LBB", lines[i]))
+    target = lines[skip].split()[-1]
+    join = next(i for i in range(skip, back) if lines[i].startswith(target + ":"))
+
+    def count(a, b):
+        n = clk = 0
+        for l in lines[a:b]:
+            if l.lstrip().startswith(";"):
+                continue
+            pr = price(l)
+            if pr:
+                n += 1; clk += pr[1]
+        return n, clk
+    always = [count(top, skip), count(join, back)]
+    tf = count(skip, join)
+    reads = sum(1 for l in lines[top:back] if "ds_read2_b32" in l)
+    return {"per_step": always[0][0] + always[1][0], "per_step_clk": always[0][1] + always[1][1],
+            "per_tf_step": tf[0], "per_tf_step_clk": tf[1], "tap_reads": reads, "lines": (top + 1, back + 1)}
+
+
 def main():
     path, a, b = sys.argv[1], int(sys.argv[2]), int(sys.argv[3])
     top = int(sys.argv[sys.argv.index("--top") + 1]) if "--top" in sys.argv else 12

@@ -40,7 +40,7 @@ def read_zip_slices(zip_bytes) -> list[bytes]:
     for info in infos:
         name = info.filename
         norm = posixpath.normpath(name)
-        if name.startswith("/") or norm.startswith(".."):        # enclosed_name(), zip.rs:56
+        if name.startswith("/") or norm == ".." or norm.startswith("../"):        # enclosed_name(), zip.rs:56 ("..foo" is a legal name)
             raise ZipReadError("ExtractFailed", "No enclosed name was able to be found")
         if info.is_dir():                        # zip.rs:57-63
             if directory is not None:
@@ -108,13 +108,22 @@ def decode_environment(data) -> tuple[np.ndarray, int, int]:
             for ch in range(4):
                 x = 0
                 while x < w:
+                    if p + 1 >= len(b):
+                        raise ValueError("Radiance map: scanline data ends inside a run")
                     n = b[p]; p += 1
-                    if n > 128:
-                        n -= 128
+                    run = n > 128
+                    n = n - 128 if run else n
+                    # a zero-length run never advances (the hang of ADVICE round 3); a run past the scanline or the
+                    # buffer is a corrupt file -- the reference's decoder (image crate) errors out in these cases too
+                    if n == 0 or x + n > w or (not run and p + n > len(b)):
+                        raise ValueError("Radiance map: corrupt run-length data")
+                    if run:
                         img[y, x:x + n, ch] = b[p]; p += 1
                     else:
                         img[y, x:x + n, ch] = np.frombuffer(b, dtype=np.uint8, count=n, offset=p); p += n
                     x += n
         else:                                                                                     # flat pixels
+            if p + 4 * w > len(b):
+                raise ValueError("Radiance map: pixel data ends early")
             img[y] = np.frombuffer(b, dtype=np.uint8, count=4 * w, offset=p).reshape(w, 4); p += 4 * w
     return _rgbe_to_float(img).reshape(-1), w, h

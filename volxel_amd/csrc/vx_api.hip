@@ -1174,6 +1174,25 @@ static int prepare_render(VxContext* c, dim3& grid) {
   c->dv.env_h = c->env_h;
   c->dv.bu_active = (eff_layout(c) == VX_LAYOUT_BRICKU8 && c->dv.bu) ? 1u : 0u;
   {
+    // The box the rays are clipped to must lie inside the volume (volume.ts:32-37 clips the volume's own box, so the
+    // viewer cannot ask for anything else): the trilinear look-up of the cellquad layout relies on every sample's cell
+    // lying in the apron lattice (Frame::trilinear, IN_LATTICE), i.e. on index positions within [-1/2, extent + 1/2).
+    // A quarter voxel of that margin is left to the rounding of ray positions near the faces.
+    const VxParams& p = c->params;
+    for (int corner = 0; corner < 8; ++corner) {
+      const float w[3] = {(corner & 1) ? p.volume_aabb_max[0] : p.volume_aabb_min[0],
+                          (corner & 2) ? p.volume_aabb_max[1] : p.volume_aabb_min[1],
+                          (corner & 4) ? p.volume_aabb_max[2] : p.volume_aabb_min[2]};
+      for (int i = 0; i < 3; ++i) {
+        const float* m = p.density_transform_inv;
+        const float q = fmaf(m[12 + i], 1.0f, fmaf(m[8 + i], w[2], fmaf(m[4 + i], w[1], m[i] * w[0])));
+        if (!(q >= -0.25f && q <= (float)c->dv.extent[i] + 0.25f))
+          VX_FAIL(c, VX_ERR_INVALID, "vx_render_frame: volume_aabb reaches index %.3f on axis %d, outside the volume [0, %u]: "
+                  "the clip box must lie inside the volume's own box (volume.ts:32-37)", (double)q, i, c->dv.extent[i]);
+      }
+    }
+  }
+  {
     // the wave-uniform terms of the primary ray (DevVolume::cam_o ...), with the operations of setup_world_ray /
     // to_index (vx_device.hpp): fma chains in the same order, IEEE divisions -- the same bits as on the device
     const VxParams& p = c->params;

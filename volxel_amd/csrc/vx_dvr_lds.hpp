@@ -279,7 +279,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(PHONG ? (SK
   // source issues at half rate, profiles/r03_op_rates.txt)
   float tile_base = 0.0f;
   const int tile_addr = (int)(uint32_t)(uintptr_t)(LdsFloatPtr)tile;   // LDS byte address of the wave's tile
-  auto axis_limit = [&](float q0a, float dqa, float iva, int lo_cell, int n_cells) {
+  [[maybe_unused]] auto axis_limit = [&](float q0a, float dqa, float iva, int lo_cell, int n_cells) {
     // cells [lo_cell, lo_cell + n_cells) are steppable: lo <= q < hi
     const float lo = (float)lo_cell, hi = lo + (float)n_cells;
     const bool bw = dqa < 0.0f;
@@ -294,6 +294,39 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(PHONG ? (SK
     const bool in1 = (q1 < face) != bw;              // forward: q1 < hi; backward: q1 >= lo
     return in1 ? c : -1.0f;
   };
+#ifndef VX_LIMITS_PER_AXIS
+  // Round 4: ONE estimate for the three axes.  ceil is monotone, so min over the axes of ceil(x_a) is ceil(min x_a): the
+  // three quotients are formed (a subtraction and a multiplication each), one min3, one ceil, one clamp at the ray's own
+  // count -- and the candidate c is confirmed on all three axes at the same index c - 1, with the very fmas the march
+  // evaluates there.  Monotone positions make every k < c inside once q(c - 1) is (the current sample is inside: `now`).
+  // Against the per-axis form (kept under -DVX_LIMITS_PER_AXIS: three ceil / clamp / select chains, 44 vector instructions
+  // per window) this is 24; it accepts a superset of the per-axis form's candidates (an axis whose own estimate was a step
+  // too high no longer vetoes a c another axis keeps below it).  Which samples are evaluated does not depend on it.
+  // the faces the ray moves towards, as offsets from the window origin: n cells ahead when it moves forwards, 0 backwards
+  const float fcx = r.dq.x < 0.0f ? 0.0f : (float)(DX - TL::LO_MARGIN - TL::HI_MARGIN);
+  const float fcy = r.dq.y < 0.0f ? 0.0f : (float)(DY - TL::LO_MARGIN - TL::HI_MARGIN);
+  const float fcz = r.dq.z < 0.0f ? 0.0f : (float)(DZ - TL::LO_MARGIN - TL::HI_MARGIN);
+  const unsigned long long bwx = ballot(r.dq.x < 0.0f), bwy = ballot(r.dq.y < 0.0f), bwz = ballot(r.dq.z < 0.0f);
+  auto set_limits = [&](bool now) {
+    const float facex = (float)(LOx + TL::LO_MARGIN) + fcx, facey = (float)(LOy + TL::LO_MARGIN) + fcy,
+                facez = (float)(LOz + TL::LO_MARGIN) + fcz;
+    const float xx = (facex - r.q0.x) * ivx, xy = (facey - r.q0.y) * ivy, xz = (facez - r.q0.z) * ivz;
+    const float c = fminf(ceilf(fminf(xx, fminf(xy, xz))), nray);     // a NaN estimate becomes n
+    const float kc = c - 1.0f;
+    // forward: q(c - 1) < hi; backward: q(c - 1) >= lo -- the compare against the face, flipped for the lanes that move backwards
+    const unsigned long long okx = ballot(fma_(kc, r.dq.x, r.q0.x) < facex) ^ bwx;
+    const unsigned long long oky = ballot(fma_(kc, r.dq.y, r.q0.y) < facey) ^ bwy;
+    const unsigned long long okz = ballot(fma_(kc, r.dq.z, r.q0.z) < facez) ^ bwz;
+    const unsigned long long ok = okx & oky & okz;
+    float k;
+    asm("v_cndmask_b32_e64 %0, %1, %2, %3" : "=v"(k) : "v"(-1.0f), "v"(c), "s"(ok));
+    k = fmaxf(k, kf + 1.0f);                         // the current sample is inside (integer test): one step at least
+    k = fminf(k, nray);
+    klim = now ? k : 0.0f;
+    tile_base = (float)(tile_addr - 4 * ((LOz * SS) + (LOy * RS) + LOx));   // |.| < 2^23: exact
+    asm volatile("" : "+v"(tile_base));
+  };
+#else
   // `now`: the lane is alive and its current sample's cell is inside the window (exact_window has just tested it)
   auto set_limits = [&](bool now) {
     const float kx = axis_limit(r.q0.x, r.dq.x, ivx, LOx + TL::LO_MARGIN, DX - TL::LO_MARGIN - TL::HI_MARGIN);
@@ -306,6 +339,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(PHONG ? (SK
     tile_base = (float)(tile_addr - 4 * ((LOz * SS) + (LOy * RS) + LOx));   // |.| < 2^23: exact
     asm volatile("" : "+v"(tile_base));
   };
+#endif
   // exact window for the lanes as they stand; lanes too far apart for one window (a wave astride two entry faces of
   // the clip box): serve the first live lane
   // returns, per lane: alive and the current sample's cell inside the window placed

@@ -254,10 +254,13 @@ function decodeEnvironment(b) {
       p += 4;
       for (let ch = 0; ch < 4; ++ch) for (let x = 0; x < w;) {
         let n = b[p++];
-        if (n > 128) { n -= 128; const v = b[p++]; for (let k = 0; k < n; ++k) px[(y * w + x + k) * 4 + ch] = v; } else { for (let k = 0; k < n; ++k) px[(y * w + x + k) * 4 + ch] = b[p++]; }
+        const run = n > 128; if (run) n -= 128;
+        // a zero-length run never advances; a run past the scanline or the buffer is a corrupt file (the image crate errors too)
+        if (n === 0 || x + n > w || p + (run ? 1 : n) > b.length) throw new Error('Radiance map: corrupt run-length data');
+        if (run) { const v = b[p++]; for (let k = 0; k < n; ++k) px[(y * w + x + k) * 4 + ch] = v; } else { for (let k = 0; k < n; ++k) px[(y * w + x + k) * 4 + ch] = b[p++]; }
         x += n;
       }
-    } else { for (let k = 0; k < 4 * w; ++k) px[y * w * 4 + k] = b[p++]; }
+    } else { if (p + 4 * w > b.length) throw new Error('Radiance map: pixel data ends early'); for (let k = 0; k < 4 * w; ++k) px[y * w * 4 + k] = b[p++]; }
   }
   const floats = new Float32Array(w * h * 4);
   for (let i = 0; i < w * h; ++i) {
