@@ -1306,13 +1306,50 @@ def test_volume_beyond_the_cellquad_index_range_is_refused(oracle):
     r.settings.render_mode = "dvr"
     r.render(); img = r.read_accum()
     assert np.isfinite(img).all()
-    # the default (VX_LAYOUT_AUTO) takes the volume: DVR on brickf32, the path-traced modes fall back to the
-    # reference textures because cellquad cannot index it
+    # the default (VX_LAYOUT_AUTO) takes the volume: DVR on brickf32, and the path-traced modes step down to the
+    # resident fp32 bricks because cellquad cannot index it (round 4: measured 2x faster than the reference textures there)
     r.set_layout(3)
     r.render(); assert np.array_equal(r.read_accum(), img)
     r.settings.render_mode = "no_dda"
     r.render(); assert np.isfinite(r.read_accum()).all()
     r.close()
+
+
+def test_auto_layout_steps_down_when_cellquad_exceeds_its_memory_budget(oracle, monkeypatch):
+    """VX_LAYOUT_AUTO builds the 18-byte-per-voxel cellquad layout for `default` / `no_dda` on first use -- only inside a
+    device-memory budget (half of the free memory; VX_AUTO_CELLQUAD_MAX_BYTES overrides).  Outside it the modes sample the
+    resident fp32 bricks: the same densities, bins and counts (layouts are bit-identical, test_golden_stochastic_modes),
+    no allocation."""
+    import torch
+    from tests.common import benchmark_tf, BENCH_CAM, small_noise
+    from volxel_amd import Volxel3DRenderer
+    vox, sp = small_noise(64, seed=9)
+    g = oracle.BrickGrid(vox, sp)
+    tf, L = benchmark_tf()
+    out = {}
+    for budget in (None, "0"):
+        if budget is None:
+            monkeypatch.delenv("VX_AUTO_CELLQUAD_MAX_BYTES", raising=False)
+        else:
+            monkeypatch.setenv("VX_AUTO_CELLQUAD_MAX_BYTES", budget)
+        r = Volxel3DRenderer(160, 96)
+        r.setup_from_grid(g)
+        r.change_transfer_func(tf, L)
+        r.settings.render_mode, r.settings.bounces = "no_dda", 2
+        r.camera.pos = np.asarray(BENCH_CAM["cam_pos"], dtype=np.float64)
+        r.camera.view = np.asarray(BENCH_CAM["look_at"], dtype=np.float64)
+        torch.cuda.synchronize()
+        before = torch.cuda.mem_get_info()[0]
+        r.reset_counters(); r.render(frames=3, in_flight=3); r.finish()
+        after = torch.cuda.mem_get_info()[0]
+        c = r.counters()
+        out[budget] = (r.read_accum(), c.samples, c.rays, before - after)
+        r.close()
+    assert np.array_equal(out[None][0], out["0"][0]) and out[None][1:3] == out["0"][1:3]
+    quads = 9 ** 3 * 576 * 16                       # (8 + 1)^3 apron bricks x 576 quads x 16 bytes
+    # the build happened inside the default budget and not with a budget of zero (everything else a first render
+    # allocates -- result slabs, counter records -- is the same in both)
+    assert out[None][3] - out["0"][3] >= quads // 2, (out[None][3], out["0"][3], quads)
 
 
 def test_context_lifecycle_releases_device_memory(oracle):

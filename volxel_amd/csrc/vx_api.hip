@@ -451,7 +451,11 @@ static int eff_layout(const VxContext* c) {
   // raymarch takes ONE nearest tap per sample (common.glsl:72-76): the 4-byte-per-voxel bricks serve it better than
   // the 18-byte-per-voxel quads, and the layout is resident already
   if (m == VX_MODE_DVR || m == VX_MODE_DVR_PHONG || m == VX_MODE_RAYMARCH) return primary_layout(c);
-  return c->auto_no_cq ? VX_LAYOUT_REFERENCE : VX_LAYOUT_CELLQUAD;
+  // `default` / `no_dda`: cellquad (18 B / voxel) while the volume is inside its index range and the build fits the device
+  // memory budget (ensure_cellquad); beyond that the fp32 bricks that are resident anyway -- eight taps per look-up, measured
+  // 1.4x / 2.0x slower than cellquad and 2.0x / 2.2x faster than the reference textures on the 1024^3 volume at 3840x2160
+  // (profiles/r04_layouts_1024.txt) -- and the reference textures only when neither native layout can index the volume
+  return c->auto_no_cq ? primary_layout(c) : VX_LAYOUT_CELLQUAD;
 }
 
 template <int MODE>
@@ -787,6 +791,20 @@ static int ensure_cellquad(VxContext* c) {
   if (c->dv.cq) return VX_OK;
   for (int i = 0; i < 3; ++i) c->dv.cq_bc[i] = c->dv.bc[i] + 1;
   const uint64_t n_quads = (uint64_t)c->dv.cq_bc[0] * c->dv.cq_bc[1] * c->dv.cq_bc[2] * CQ_BRICK_QUADS;
+  if (c->layout == VX_LAYOUT_AUTO) {
+    // AUTO builds this layout on demand, beside what is resident: only when it leaves half of the free device memory to
+    // the rest of the process (19.8 GB for 1024^3 on a 288 GB MI355X: always; a volume near the layout's 64 GiB index limit
+    // on a device that other contexts share: not necessarily).  Otherwise `default` / `no_dda` take the resident bricks.
+    // VX_AUTO_CELLQUAD_MAX_BYTES (environment, read here) overrides the budget -- 0 keeps AUTO off this layout.
+    size_t free_b = 0, total_b = 0;
+    VX_HIP(c, hipMemGetInfo(&free_b, &total_b));
+    uint64_t budget = (uint64_t)free_b / 2u;
+    if (const char* e = getenv("VX_AUTO_CELLQUAD_MAX_BYTES")) budget = strtoull(e, nullptr, 10);
+    if (n_quads * sizeof(float4) > budget) {
+      c->auto_no_cq = true;
+      return VX_OK;
+    }
+  }
   VX_HIP(c, hipMalloc(&c->cq_alloc, n_quads * sizeof(float4)));
   c->dv.cq = (const float4*)c->cq_alloc;
   for (uint64_t at = 0; at < n_quads;) {
@@ -1227,9 +1245,12 @@ static int prepare_render(VxContext* c, dim3& grid) {
   }
   {
     // the layouts this launch samples, built on first use beside the one the upload built
-    const int lay = eff_layout(c);
+    int lay = eff_layout(c);
     int rc = VX_OK;
-    if (lay == VX_LAYOUT_CELLQUAD) rc = ensure_cellquad(c);
+    if (lay == VX_LAYOUT_CELLQUAD) {
+      rc = ensure_cellquad(c);
+      lay = eff_layout(c);   // AUTO may have stepped down to the resident bricks (memory budget)
+    }
     if (!rc && (lay == VX_LAYOUT_BRICKF32 ||
                 (c->params.render_mode == VX_MODE_DVR_PHONG && lay == VX_LAYOUT_CELLQUAD && tuned_possible(c))))
       rc = ensure_brickf32(c);
