@@ -1315,6 +1315,38 @@ def test_volume_beyond_the_cellquad_index_range_is_refused(oracle):
     r.close()
 
 
+@pytest.mark.parametrize("res", [(1920, 1080), (333, 251), (1000, 7), (4096, 16)])
+def test_host_decided_ray_divisions_are_exact(oracle, monkeypatch, res):
+    """round 4: two of a primary ray's divisions are decided per launch on the host (DevVolume::ray_flags): the three divisions by
+    the w of inverse(view) * (v, 1) are skipped when that w is 1.0 by construction, and (pixel + 0.5) / res becomes a
+    reciprocal product corrected by its remainder when the host found that form equal to the IEEE division for EVERY pixel
+    coordinate of the resolution.  VX_RAY_SHORTCUTS=0 keeps the divisions: debugHits (the entry point of every primary ray, jitter
+    included) and a jittered DVR frame must not move by a bit, whatever the resolution."""
+    from tests.common import benchmark_tf, BENCH_CAM, small_noise
+    from volxel_amd import Volxel3DRenderer
+    vox, sp = small_noise(32, seed=4)
+    g = oracle.BrickGrid(vox, sp)
+    tf, L = benchmark_tf()
+    out = {}
+    for sc in ("1", "0"):
+        monkeypatch.setenv("VX_RAY_SHORTCUTS", sc)
+        r = Volxel3DRenderer(*res)
+        r.setup_from_grid(g)
+        r.change_transfer_func(tf, L)
+        r.camera.pos = np.asarray(BENCH_CAM["cam_pos"], dtype=np.float64)
+        r.camera.view = np.asarray(BENCH_CAM["look_at"], dtype=np.float64)
+        imgs = []
+        for mode, dbg in (("dvr", True), ("dvr", False), ("no_dda", False)):
+            r.settings.render_mode, r.settings.debug_hits, r.settings.dvr_jitter = mode, dbg, True
+            r.restart_rendering(); r.reset_counters()
+            r.render(frames=3, in_flight=3)
+            imgs.append((r.read_accum(), r.counters().samples))
+        out[sc] = imgs
+        r.close()
+    for (a, na), (b, nb) in zip(out["1"], out["0"]):
+        assert np.array_equal(a, b) and na == nb
+
+
 def test_auto_layout_steps_down_when_cellquad_exceeds_its_memory_budget(oracle, monkeypatch):
     """VX_LAYOUT_AUTO builds the 18-byte-per-voxel cellquad layout for `default` / `no_dda` on first use -- only inside a
     device-memory budget (half of the free memory; VX_AUTO_CELLQUAD_MAX_BYTES overrides).  Outside it the modes sample the

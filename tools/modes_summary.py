@@ -11,6 +11,17 @@ root = sys.argv[1]
 print(f"# rocprofv3 --pmc (two passes per mode, counters only) of the reference render modes on config 3, 1080p, default")
 print(f"# environment map, bounces 1, 16 frames per launch (tools/modes_pmc.sh, tools/mode_profile.py); values of the")
 print(f"# largest launch; ms per frame from the library's HIP events in the same runs")
+json_out = None
+if "--json" in sys.argv:
+    i = sys.argv.index("--json"); json_out = sys.argv[i + 1]; src_name = sys.argv[i + 2]
+    import json
+    db = {"_note": "lane utilisation of the reference render modes on the bench scene (config 3: 512^3, 1920x1080, bounces 1, default "
+                   "environment map): SQ_THREAD_CYCLES_VALU / (64 x SQ_ACTIVE_INST_VALU) of the rocprofv3 PMC passes of tools/modes_pmc.sh "
+                   "(16 frames per launch); bench.py copies these into config.other_modes when the scene matches (source named per entry)"}
+    try:
+        old_db = json.load(open(json_out))
+    except Exception:
+        old_db = {}
 for mode in ("default", "no_dda", "raymarch"):
     vals, meta = {}, {}
     for grp in ("sq", "mem"):
@@ -50,3 +61,13 @@ for mode in ("default", "no_dda", "raymarch"):
     if "TD_TD_BUSY_sum" in vals and "GRBM_GUI_ACTIVE" in vals:
         d.append(f"TD busy {vals['TD_TD_BUSY_sum'] / (vals['GRBM_GUI_ACTIVE'] / 8.0 * 256):.2f}")
     print("# derived: " + "; ".join(d))
+    if json_out and "SQ_THREAD_CYCLES_VALU" in vals and "SQ_ACTIVE_INST_VALU" in vals:
+        e = dict(old_db.get(mode, {}))          # keeps the L1 / L2 / HBM figures of tools/modes_l2.sh, if any
+        e.update({"width": 1920, "height": 1080, "volume": 512,
+                  "lane_utilisation": round(vals["SQ_THREAD_CYCLES_VALU"] / (64 * vals["SQ_ACTIVE_INST_VALU"]), 3),
+                  "valu_issue_of_clocks": (round(vals["SQ_INSTS_VALU"] * 2.0 / (vals["GRBM_GUI_ACTIVE"] / 8.0 * 1024), 3)
+                                           if "GRBM_GUI_ACTIVE" in vals else None),
+                  "kernel": km[0].replace("kernel void ", ""), "source": src_name})
+        db[mode] = e
+if json_out:
+    json.dump(db, open(json_out, "w"), indent=1)

@@ -1224,6 +1224,21 @@ static int prepare_render(VxContext* c, dim3& grid) {
     for (int i = 0; i < 3; ++i) c->dv.cam_ipos[i] = a[i];
     c->dv.inv_res[0] = 1.0f / (float)p.res[0];
     c->dv.inv_res[1] = 1.0f / (float)p.res[1];
+    // the per-ray divisions a launch constant decides (DevVolume::ray_flags): both shortcuts are exact or not taken
+    uint32_t flags = 0;
+    const float* vi = p.camera_view_inv;
+    if (vi[3] == 0.0f && vi[7] == 0.0f && vi[11] == 0.0f && vi[15] == 1.0f) flags |= RAY_AFFINE_VIEW;
+    for (int axis = 0; axis < 2; ++axis) {
+      const float res = (float)p.res[axis], y = c->dv.inv_res[axis];
+      bool same = true;
+      for (int px = 0; px < p.res[axis] && same; ++px) {
+        const float a = (float)px + 0.5f, q0 = a * y;
+        same = fmaf(fmaf(-res, q0, a), y, q0) == a / res;
+      }
+      if (same) flags |= (axis == 0 ? RAY_TEX_BY_RECIPROCAL_X : RAY_TEX_BY_RECIPROCAL_Y);
+    }
+    if (getenv("VX_RAY_SHORTCUTS") && atoi(getenv("VX_RAY_SHORTCUTS")) == 0) flags = 0;   // diagnostic: the divisions themselves
+    c->dv.ray_flags = flags;
   }
   {
     const VxParams& p = c->params;

@@ -64,7 +64,15 @@ struct DevVolume {
   float cam_o[3];               // inverse(view) * (0,0,0,1), divided by w          (utils.glsl:25-27)
   float cam_ipos[3];            // density_transform_inv * (cam_o, 1)               (to_index of the origin)
   float inv_res[2];             // 1 / u_res
+  // Round 4: two more per-ray divisions decided per launch on the host (vx_api.hip prepare_render), both exact:
+  //  * RAY_AFFINE_VIEW: inverse(view) has the bottom row (0,0,0,1), so the w of inverse(view) * (v, 1) is fma(1, 1, 0 * ...)
+  //    = 1.0 and the three divisions by it (utils.glsl:35-37) return their numerators;
+  //  * RAY_TEX_BY_RECIPROCAL: (pixel + 0.5) / res over the whole image equals the quotient corrected once with the rounded
+  //    reciprocal -- q0 = a * y, q = fma(fma(-res, q0, a), y, q0) -- for EVERY pixel coordinate of this resolution (the host
+  //    tries all of them against the IEEE division; a resolution for which one differs keeps the division).
+  uint32_t ray_flags;
 };
+constexpr uint32_t RAY_AFFINE_VIEW = 1u, RAY_TEX_BY_RECIPROCAL_X = 2u, RAY_TEX_BY_RECIPROCAL_Y = 4u;
 
 constexpr uint32_t IMP_DIM = 512, IMP_LEVELS = 10, IMP_FLOATS = 349525;
 // quads of level k (children of the texels of level k+1): (IMP_DIM >> (k+1))^2 float4, row major
@@ -505,6 +513,17 @@ VXD bool ray_box_intersection(const Ray& r, const float* bmin, const float* bmax
   return near <= far;
 }
 
+// fragment.frag:131 `(pixel + 0.5) / u_res` for one axis; with the host's go-ahead the IEEE division sequence (ten vector
+// instructions) is the reciprocal product corrected by its own remainder (three), the same bits for every pixel of the image
+VXD float tex_coord(int pixel, int res, const DevVolume* hv, int axis) {
+  const float a = (float)pixel + 0.5f;
+  if (hv && (hv->ray_flags & (axis == 0 ? RAY_TEX_BY_RECIPROCAL_X : RAY_TEX_BY_RECIPROCAL_Y))) {   // wave uniform
+    const float y = hv->inv_res[axis], q0 = a * y;
+    return fma_(fma_(-(float)res, q0, a), y, q0);
+  }
+  return a / (float)res;
+}
+
 // A9: setup_world_ray, fragment.frag:57-65 + utils.glsl:23-40, inverses hoisted (Q11)
 // hv: the host-evaluated uniform terms (DevVolume::cam_o ...), or nullptr to evaluate them here -- the same bits
 VXD Ray setup_world_ray(const VxParams& p, float tex_x, float tex_y, float rx, float ry, const DevVolume* hv = nullptr) {
@@ -528,7 +547,9 @@ VXD Ray setup_world_ray(const VxParams& p, float tex_x, float tex_y, float rx, f
   mat4_mul(p.camera_proj_inv, fma_(sx, 2.0f, -1.0f), fma_(sy, 2.0f, -1.0f), 0.0f, 1.0f, vp);
   float vx_ = vp[0] / vp[3], vy_ = vp[1] / vp[3], vz_ = vp[2] / vp[3];
   mat4_mul(p.camera_view_inv, vx_, vy_, vz_, 1.0f, wp);
-  V3 world = v3(wp[0] / wp[3], wp[1] / wp[3], wp[2] / wp[3]);
+  V3 world;
+  if (hv && (hv->ray_flags & RAY_AFFINE_VIEW)) world = v3(wp[0], wp[1], wp[2]);   // wp[3] == 1.0: x / 1 = x (wave uniform)
+  else world = v3(wp[0] / wp[3], wp[1] / wp[3], wp[2] / wp[3]);
   return Ray{cam, normalize3(sub3(world, cam))};
 }
 

@@ -24,8 +24,8 @@ struct DvrRay {
 };
 
 VXD DvrRay dvr_setup(const VxParams& p, const DevVolume& v, int px, int py, uint32_t frame) {
-  float tex_x = ((float)px + 0.5f) / (float)p.res[0];
-  float tex_y = ((float)py + 0.5f) / (float)p.res[1];
+  float tex_x = tex_coord(px, p.res[0], &v, 0);
+  float tex_y = tex_coord(py, p.res[1], &v, 1);
   float jx = 0.5f, jy = 0.5f, off = 0.5f;
   if (p.dvr_jitter) {  // wave-uniform: the integer RNG (32 TEA rounds) only runs when it is used
     Rng s = seed_xoshiro(tea32(42u * (uint32_t)(py * p.res[0] + px), frame));

@@ -658,12 +658,20 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(PHONG ? (SK
       }
     }
 #endif
-    more = (s < S) & (gom != 0ull);   // somebody can still step in this window
+    // The window is left when fewer than VX_LDS_MIN_ACTIVE lanes can still step in it (1: when nobody can): the stragglers'
+    // steps are taken in the next window, which is anchored at them anyway -- which samples are evaluated does not change.
+#ifndef VX_LDS_MIN_ACTIVE
+#define VX_LDS_MIN_ACTIVE 1
+#endif
+    auto enough = [&]() {
+      return VX_LDS_MIN_ACTIVE <= 1 ? (gom != 0ull) : (__builtin_popcountll(gom) >= VX_LDS_MIN_ACTIVE);
+    };
+    more = (s < S) & ((s == 0) ? (gom != 0ull) : enough());   // the first trip of a window always has a lane that steps
     if (more) {
 #pragma unroll 1
       do {
         step(std::false_type{});
-        more = (s < S) & (gom != 0ull);
+        more = (s < S) & enough();
       } while (more);
     }
   };

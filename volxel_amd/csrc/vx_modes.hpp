@@ -426,8 +426,8 @@ struct Frame {
   template <int MODE>
   VXD float4 shade_pixel(int px, int py, uint32_t frame) const {
     Rng s = seed_xoshiro(tea32(42u * (uint32_t)(py * p.res[0] + px), frame));  // :143-144
-    float tex_x = ((float)px + 0.5f) / (float)p.res[0];
-    float tex_y = ((float)py + 0.5f) / (float)p.res[1];
+    float tex_x = tex_coord(px, p.res[0], &v, 0);
+    float tex_y = tex_coord(py, p.res[1], &v, 1);
     float a0 = rng(s), a1 = rng(s), b0 = rng(s), b1 = rng(s);  // :146
     float jx = (a0 + b0) / 2.0f, jy = (a1 + b1) / 2.0f;
     constexpr bool DVR = (MODE == VX_MODE_DVR || MODE == VX_MODE_DVR_PHONG);
