@@ -1315,6 +1315,42 @@ def test_volume_beyond_the_cellquad_index_range_is_refused(oracle):
     r.close()
 
 
+def test_shared_window_kernel_is_bit_identical(oracle, monkeypatch):
+    """VX_DVR_WG=1 (vx_dvr_lds.hpp, WG): in launches of a multiple of 32 frames the four waves of a workgroup take the same 8
+    pixels (8 frames each) and march through ONE window four times the volume, placed through an exchange in LDS and two
+    workgroup barriers per window -- the north star's "per-workgroup LDS staging of the active brick", literally.  Same
+    image bits and counters as the shipped wave-private windows: jittered frames, clip box, ERT, a ragged image (partial
+    tiles: waves without a live ray must still meet every barrier), 32 and 64 frames in flight, and a 40-frame request
+    (32 through the shared window, 8 through the wave-private one)."""
+    from tests.common import benchmark_tf, BENCH_CAM, small_noise
+    from volxel_amd import Volxel3DRenderer
+    vox, sp = small_noise(64, seed=11)
+    g = oracle.BrickGrid(vox, sp)
+    tf, L = benchmark_tf()
+    res = {}
+    for wg in ("0", "1"):
+        monkeypatch.setenv("VX_DVR_WG", wg)
+        out = []
+        for (W, H), frames, fpl in (((200, 136), 32, 32), ((333, 77), 64, 64), ((96, 64), 40, 32)):
+            r = Volxel3DRenderer(W, H)
+            r.setup_from_grid(g)
+            r.change_transfer_func(tf, L)
+            r.settings.render_mode, r.settings.dvr_jitter, r.settings.dvr_skip_empty = "dvr", True, False
+            r.settings.volume_clip_min, r.settings.volume_clip_max = (0.25, 0.0, 0.0), (1.0, 1.0, 0.75)
+            r.settings.sample_range = (0.05, 1.0)
+            r.camera.pos = np.asarray(BENCH_CAM["cam_pos"], dtype=np.float64)
+            r.camera.view = np.asarray(BENCH_CAM["look_at"], dtype=np.float64)
+            r.reset_counters()
+            r.render(frames=frames, in_flight=fpl); r.finish()
+            c = r.counters()
+            out.append((r.read_accum(), c.samples, c.tf_samples, c.rays, c.pixels))
+            r.close()
+        res[wg] = out
+    for a, b in zip(res["0"], res["1"]):
+        assert np.array_equal(a[0], b[0]) and a[1:] == b[1:]
+        assert a[1] > 0
+
+
 @pytest.mark.parametrize("res", [(1920, 1080), (333, 251), (1000, 7), (4096, 16)])
 def test_host_decided_ray_divisions_are_exact(oracle, monkeypatch, res):
     """round 4: two of a primary ray's divisions are decided per launch on the host (DevVolume::ray_flags): the three divisions by

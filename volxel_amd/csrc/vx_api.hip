@@ -94,6 +94,7 @@ struct VxContext {
   size_t dc_waves = 0;
   uint32_t* order = nullptr;   // launch permutation of the DVR kernel (build_order), dc_waves/4 entries
   bool use_order = true;
+  bool dvr_shared_window = false;    // VX_DVR_WG=1: one LDS window per workgroup in launches of a multiple of 32 frames (vx_dvr_lds.hpp, WG)
   int order_builds_left = 2;   // rebuild the order after the first frames that follow a change
   VxCounters base{};           // totals folded in when the record array is reallocated
   std::vector<EventPair> free_events, pending_events;
@@ -609,6 +610,8 @@ int vx_create(int device_id, VxContext** out) {
   if (pk && !strcmp(pk, "events")) c->paths_variant = 3;     // wave-persistent, event-batched (vx_events.hpp): measured slower
   const char* dpe = getenv("VX_DVR_DP");
   if (dpe) c->dp_env = atoi(dpe);
+  const char* wg = getenv("VX_DVR_WG");
+  if (wg) c->dvr_shared_window = atoi(wg) != 0;
   const char* o = getenv("VX_DVR_ORDER");
   if (o && !strcmp(o, "0")) c->use_order = false;
   *out = c;
@@ -1432,7 +1435,7 @@ int vx_render_frames(VxContext* c, uint32_t first_frame, uint32_t count, const f
                             c->use_order ? c->order : nullptr);
       else if (tuned_lds)
         launch_dvr_lds(c->params, c->dv, c->tf, c->tf_len, mo, 0.0f, c->tm, c->stream,
-                       c->use_order ? c->order : nullptr);
+                       c->use_order ? c->order : nullptr, c->dvr_shared_window);
       else
         launch_generic_mode(c, mo, 0.0f, grid, c->stream);
       le = hipGetLastError();

@@ -52,7 +52,10 @@ namespace vx {
 #ifndef VX_LDS_S_PHONG   // steps per window of the shading kernel: with one frame's 64 pixels per wave 12 / 16 / 20 / 24 gave
 #define VX_LDS_S_PHONG 16  // 0.365 / 0.370 / 0.375 / 0.377 ms per frame; with lanes = pixels x frames 12 / 16 / 20: 0.335 / 0.327 / 0.329
 #endif
-template <bool PHONG>
+#ifndef VX_LDS_WGD   // y / z size of a window the four waves of a workgroup share (WG builds): 16 x 16 rows = 64 per wave
+#define VX_LDS_WGD 16
+#endif
+template <bool PHONG, bool WG = false>
 struct LdsTile {
   static constexpr int X = VX_LDS_X;             // X / 4 chunks of 16 bytes per row
 #ifndef VX_LDS_DY   // windows that are not square in (y, z), with lanes = pixels x frames, config 3, ms per frame at 32 frames per
@@ -63,13 +66,14 @@ struct LdsTile {
 #ifndef VX_LDS_DZ
 #define VX_LDS_DZ VX_LDS_D
 #endif
-  static constexpr int Y = PHONG ? VX_LDS_DP : VX_LDS_DY;
-  static constexpr int Z = PHONG ? VX_LDS_DP : VX_LDS_DZ;
+  static constexpr int Y = WG ? VX_LDS_WGD : (PHONG ? VX_LDS_DP : VX_LDS_DY);
+  static constexpr int Z = WG ? VX_LDS_WGD : (PHONG ? VX_LDS_DP : VX_LDS_DZ);
   static constexpr int RS = (X % 8 == 4) ? X : X + 4;             // row stride in words, = 4 mod 8
   static constexpr int SS = (Y * RS + 31 - 28) / 32 * 32 + 28;    // slice stride in words: >= Y * RS, = 28 mod 32
   static constexpr int ROWS = Y * Z;
   static constexpr int FLOATS = SS * Z;          // 3968 B (DVR) / 4960 B (Phong) per wave
-  static constexpr int PASSES = (ROWS + 63) / 64;
+  static constexpr int PASSES = WG ? 1 : (ROWS + 63) / 64;   // WG: wave w stages rows 64 w .. 64 w + 63
+  static_assert(!WG || ROWS == 256, "a shared window is staged by four waves, 64 rows each");
   static constexpr int LO_MARGIN = PHONG ? 1 : 0;   // cells below the sample's cell that must be resident
   static constexpr int HI_MARGIN = PHONG ? 2 : 1;   // taps above it (x+1; x+2 for the gradient)
   static_assert(SS >= Y * RS && SS % 4 == 0 && RS % 4 == 0 && RS >= X && X % 4 == 0, "tile strides");
@@ -139,17 +143,33 @@ typedef const float __attribute__((address_space(3))) * LdsFloatPtr;
 // U8: the window is staged from the bricku8 layout (8-bit codes + a range per brick, decoded here with A4's fma) instead
 // of brickf32's fp32 voxels -- the dword index of a 4-voxel chunk is brickf32's 16-byte-unit index, so the row and chunk
 // arithmetic is shared; everything after the staging is the same code on the same values.
-template <int S, bool PHONG, bool SKIP, bool U8 = false>
+// WG (round 4): ONE window per workgroup.  In a launch of a multiple of 32 frames the four waves of a workgroup take the SAME 8
+// pixels (8 frames each): 256 rays of one narrow beam.  They place one window four times the volume of a wave's (12 x 16 x 16),
+// each wave stages a quarter of its rows, and every lane marches in it -- 1.7x the steps per window for the same staging work
+// per wave.  The cost is two workgroup barriers per window (the anchor's minima go through LDS; nobody may restage a tile a
+// sister wave still reads).  Every barrier sits on a workgroup-uniform path: the loop ends for all four waves together, when
+// the minima in LDS say no wave has a live ray.  Which samples a ray evaluates is untouched: same bits
+// (tests/test_gpu_parity.py::test_shared_window_kernel_is_bit_identical).
+// MEASURED (profiles/r04_shared_window.txt), config 3, 32 frames per launch: wave-windows per frame 235 955 -> 146 521 (0.62x), lane
+// utilisation 0.936 -> 0.924 (a longer window has a longer tail of lanes that have left it), and 0.2040-0.2086 ms per frame against
+// 0.2045-0.2074 for the wave-private windows on the same boxes: the windows it saves (7 % of the vector work by the listing's
+// prices) go into the exchange through LDS (~100 clocks per window and wave), the idle lane slots and the barrier skew.
+// Not faster: it stays OPT-IN (VX_DVR_WG=1).
+template <int S, bool PHONG, bool SKIP, bool U8 = false, bool WG = false>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(PHONG ? (SKIP ? 1 : VX_W_LDS_PHONG) : (SKIP ? VX_W_LDS_SKIP : VX_W_LDS), 8))) void render_dvr_lds(const VxParams p, const DevVolume v,
                                                        const float4* __restrict__ tf_global, uint32_t tf_len,
                                                        const MultiOut mo, float weight, const TileMap tm,
                                                        const uint32_t* __restrict__ order) {
-  using TL = LdsTile<PHONG>;
+  static_assert(!WG || (!SKIP && !PHONG), "the shared window serves the plain DVR march");
+  using TL = LdsTile<PHONG, WG>;
   constexpr int DX = TL::X, DY = TL::Y, DZ = TL::Z, RS = TL::RS, SS = TL::SS;
   extern __shared__ float4 lds_raw[];
   float4* tf_lds = lds_raw;
   uint32_t* mask_lds = reinterpret_cast<uint32_t*>(lds_raw + tf_len);
-  float* tile = reinterpret_cast<float*>(mask_lds + (SKIP ? ((v.skip_words + 3u) & ~3u) : 0u)) + (threadIdx.x >> 6) * TL::FLOATS;
+  float* tile = reinterpret_cast<float*>(mask_lds + (SKIP ? ((v.skip_words + 3u) & ~3u) : 0u)) + (WG ? 0u : (threadIdx.x >> 6) * TL::FLOATS);
+  // WG: behind the shared tile, per wave {min x, min y, min z, first live lane's cell x, y, z, live | direction bits, -}
+  int* const wg_box = reinterpret_cast<int*>(tile + TL::FLOATS);
+  const uint32_t wave = threadIdx.x >> 6;
   for (uint32_t i = threadIdx.x; i < tf_len; i += blockDim.x) tf_lds[i] = tf_global[i];
   if (SKIP)
     for (uint32_t i = threadIdx.x; i < v.skip_words; i += blockDim.x) mask_lds[i] = v.skip_bits[i];
@@ -162,12 +182,19 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(PHONG ? (SK
   const uint32_t frame = mo.frame[fslot];
   uint32_t lt, sub;
   if (!block_to_tile(blk, tm, lt, sub)) return;
-  const uint32_t wt = sub * 4u + (threadIdx.x >> 6), lane = threadIdx.x & 63u;
+  uint32_t wt = sub * 4u + (threadIdx.x >> 6);
+  const uint32_t lane = threadIdx.x & 63u;
   uint32_t plane = lane, my_frame = frame;
 #ifndef VX_DVR_FL_MAXSH   // groups of up to 2^3 frame slots: 8 pixels x 8 frames per wave (groups of 16 / 32 measured within 1 %:
 #define VX_DVR_FL_MAXSH 3 // ms per frame at 20 / 32 frames per launch 0.2244 / 0.2169 against 0.2216-0.2245 / 0.2150-0.2185)
 #endif
-  if (mo.count > 1u) {   // lanes = pixels x frames (vx_kernels.hpp frame_group)
+  if (WG) {   // (the launcher only takes this build for a multiple of 32 frames) the workgroup at slot r of a group of 32 takes
+              // wave tile r >> 3 of its block position and pixel octet r & 7; its four waves take 8 frames of the group each
+    const uint32_t r = fslot & 31u;
+    wt = sub * 4u + (r >> 3);
+    plane = ((r & 7u) << 3) + (lane & 7u);
+    slab = lane_frame_slot((fslot - r) + wave * 8u + (lane >> 3), my_frame);
+  } else if (mo.count > 1u) {   // lanes = pixels x frames (vx_kernels.hpp frame_group)
     uint32_t base;
     const uint32_t sh = frame_group<VX_DVR_FL_MAXSH>(fslot, mo.count, base);
     if (sh != 0u) {
@@ -241,6 +268,14 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(PHONG ? (SK
       fwx = __builtin_amdgcn_readlane(__builtin_bit_cast(int, r.dq.x), first) >= 0;   // sign bit clear
       fwy = __builtin_amdgcn_readlane(__builtin_bit_cast(int, r.dq.y), first) >= 0;
       fwz = __builtin_amdgcn_readlane(__builtin_bit_cast(int, r.dq.z), first) >= 0;
+    }
+    if (WG) {   // one direction for the workgroup: that of the lowest wave with a live ray
+      if (lane == 0u) wg_box[wave * 8u + 6u] = live0 != 0ull ? (1 | (fwx ? 2 : 0) | (fwy ? 4 : 0) | (fwz ? 8 : 0)) : 0;
+      __syncthreads();
+      const int d0 = wg_box[6], d1 = wg_box[14], d2 = wg_box[22], d3 = wg_box[30];
+      const int d = __builtin_amdgcn_readfirstlane(d0 ? d0 : (d1 ? d1 : (d2 ? d2 : d3)));
+      fwx = (d & 2) != 0 || d == 0; fwy = (d & 4) != 0 || d == 0; fwz = (d & 8) != 0 || d == 0;
+      __syncthreads();   // the slots are written again by the first window
     }
   }
   int LOx = 0, LOy = 0, LOz = 0;   // origin of the resident window (wave uniform)
@@ -343,9 +378,51 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(PHONG ? (SK
   // exact window for the lanes as they stand; lanes too far apart for one window (a wave astride two entry faces of
   // the clip box): serve the first live lane
   // returns, per lane: alive and the current sample's cell inside the window placed
-  auto exact_window = [&](unsigned long long live) {
+  bool wg_any = true;   // WG: some wave of the workgroup has a live ray (workgroup uniform, from the minima in LDS)
+  auto exact_window = [&](unsigned long long live) -> bool {
     const bool alive = is_alive();
     const int cxi = (int)flx, cyi = (int)fly, czi = (int)flz;
+    if (WG) {
+      // the wave's extreme cells and its first live lane's cell go through LDS; the barrier behind the writes is also the
+      // point after which no wave reads the resident tile any more (every wave has left its march)
+      int ex_ = alive ? (fwx ? cxi : -cxi) : 0x7fffffff, ey_ = alive ? (fwy ? cyi : -cyi) : 0x7fffffff,
+          ez_ = alive ? (fwz ? czi : -czi) : 0x7fffffff;
+      wave_min3(ex_, ey_, ez_);
+      const int first = live != 0ull ? (int)__builtin_ctzll(live) : 0;
+      const int fx_ = __builtin_amdgcn_readlane(cxi, first), fy_ = __builtin_amdgcn_readlane(cyi, first),
+                fz_ = __builtin_amdgcn_readlane(czi, first);
+      if (lane == 0u) {
+        int* b = wg_box + wave * 8u;
+        b[0] = ex_; b[1] = ey_; b[2] = ez_; b[3] = fx_; b[4] = fy_; b[5] = fz_; b[6] = live != 0ull ? 1 : 0;
+      }
+      __syncthreads();
+      auto mn = [](int a, int b) { return a < b ? a : b; };
+      const int gx = __builtin_amdgcn_readfirstlane(mn(mn(wg_box[0], wg_box[8]), mn(wg_box[16], wg_box[24])));
+      const int gy = __builtin_amdgcn_readfirstlane(mn(mn(wg_box[1], wg_box[9]), mn(wg_box[17], wg_box[25])));
+      const int gz = __builtin_amdgcn_readfirstlane(mn(mn(wg_box[2], wg_box[10]), mn(wg_box[18], wg_box[26])));
+      const int l0 = wg_box[6], l1 = wg_box[14], l2 = wg_box[22], l3 = wg_box[30];
+      const int fw = __builtin_amdgcn_readfirstlane(l0 ? 0 : (l1 ? 1 : (l2 ? 2 : (l3 ? 3 : -1))));   // lowest wave with a live ray
+      wg_any = fw >= 0;
+      if (!wg_any) return false;
+      LOx = fwx ? gx - TL::LO_MARGIN : -gx + TL::HI_MARGIN - (DX - 1);
+      LOy = fwy ? gy - TL::LO_MARGIN : -gy + TL::HI_MARGIN - (DY - 1);
+      LOz = fwz ? gz - TL::LO_MARGIN : -gz + TL::HI_MARGIN - (DZ - 1);
+      LOx = fwx ? (LOx & ~3) : ((LOx + 3) & ~3);
+      // progress: the window must hold the first live lane of that wave (rays too far apart for one window -- a workgroup
+      // astride two entry faces of the clip box -- are served one neighbourhood at a time); every wave decides alike
+      const int ax = __builtin_amdgcn_readfirstlane(wg_box[fw * 8 + 3]), ay = __builtin_amdgcn_readfirstlane(wg_box[fw * 8 + 4]),
+                az = __builtin_amdgcn_readfirstlane(wg_box[fw * 8 + 5]);
+      const uint32_t rx = (uint32_t)(ax - LOx - TL::LO_MARGIN), ry = (uint32_t)(ay - LOy - TL::LO_MARGIN),
+                     rz = (uint32_t)(az - LOz - TL::LO_MARGIN);
+      if (!((rx < (uint32_t)(DX - TL::LO_MARGIN - TL::HI_MARGIN)) & (ry < (uint32_t)(DY - TL::LO_MARGIN - TL::HI_MARGIN)) &
+            (rz < (uint32_t)(DZ - TL::LO_MARGIN - TL::HI_MARGIN)))) {
+        LOx = ax - TL::LO_MARGIN - (fwx ? 0 : DX - 1 - TL::LO_MARGIN - TL::HI_MARGIN);
+        LOx = fwx ? (LOx & ~3) : ((LOx + 3) & ~3);
+        LOy = ay - TL::LO_MARGIN - (fwy ? 0 : DY - 1 - TL::LO_MARGIN - TL::HI_MARGIN);
+        LOz = az - TL::LO_MARGIN - (fwz ? 0 : DZ - 1 - TL::LO_MARGIN - TL::HI_MARGIN);
+      }
+      return (bool)(alive & inside_of(LOx, LOy, LOz, cxi, cyi, czi));
+    }
     anchor(alive, cxi, cyi, czi, 0, LOx, LOy, LOz);
     bool now = alive & inside_of(LOx, LOy, LOz, cxi, cyi, czi);
     if (ballot(now) == 0ull) {
@@ -372,7 +449,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(PHONG ? (SK
     }
 #pragma unroll
     for (int ps = 0; ps < TL::PASSES; ++ps) {
-      const uint32_t row = lane + 64u * (uint32_t)ps;
+      const uint32_t row = lane + 64u * (WG ? wave : (uint32_t)ps);
       const uint32_t zz = row / (uint32_t)DY, yy = row - zz * (uint32_t)DY;
       const int gy = oy + (int)yy, gz = oz + (int)zz;
       const bool rin = row < (uint32_t)TL::ROWS && (uint32_t)gy < ey && (uint32_t)gz < ez;
@@ -413,11 +490,13 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(PHONG ? (SK
   };
   // stage, part 2: the rows into the wave's tile
   auto write_tile = [&](float4 (&vals)[TL::PASSES][NC]) {
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");   // earlier tile reads are done
-    __builtin_amdgcn_wave_barrier();
+    if (!WG) {   // (WG: the barrier of exact_window already separates the old tile's reads from these writes)
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");   // earlier tile reads are done
+      __builtin_amdgcn_wave_barrier();
+    }
 #pragma unroll
     for (int ps = 0; ps < TL::PASSES; ++ps) {
-      const uint32_t row = lane + 64u * (uint32_t)ps;
+      const uint32_t row = lane + 64u * (WG ? wave : (uint32_t)ps);
       if (row < (uint32_t)TL::ROWS) {
         const uint32_t zz = row / (uint32_t)DY, yy = row - zz * (uint32_t)DY;
         float4* dst = reinterpret_cast<float4*>(tile + zz * (uint32_t)SS + yy * (uint32_t)RS);
@@ -425,9 +504,13 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(PHONG ? (SK
         for (int c = 0; c < NC; ++c) dst[c] = vals[ps][c];
       }
     }
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-    __builtin_amdgcn_wave_barrier();
-    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    if (WG) {
+      __syncthreads();   // the four quarters of the tile are in place
+    } else {
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+      __builtin_amdgcn_wave_barrier();
+      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    }
   };
 
   // ---- SKIP: exact empty-space skipping (A12 note: a sample in a macro cell that can only see TF-transparent bricks
@@ -499,6 +582,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(PHONG ? (SK
       if (live == 0ull) return false;
     }
     const bool now = exact_window(live);
+    if (WG && !wg_any) return false;   // workgroup uniform: no wave has a live ray left
     if (SKIP) wtest = touches_empty();
     set_limits(now);
     float4 vals[TL::PASSES][NC];
@@ -507,11 +591,11 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(PHONG ? (SK
     return true;
   };
 
+  bool wg_go = true;
   {
     const unsigned long long live = ballot(is_alive());
-    if (live != 0ull) {
-      (void)next_window(live);
-    }
+    if (WG) wg_go = next_window(live);   // every wave takes part in every window of its workgroup
+    else if (live != 0ull) (void)next_window(live);
   }
   // ---- 3. march: up to S steps out of LDS.  TEST (SKIP builds): the window touches an empty macro cell, the mask is
   // tested per step; in the other windows the test is compiled out.
@@ -675,15 +759,15 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(PHONG ? (SK
       } while (more);
     }
   };
-  while (true) {
-    if (ballot(is_alive()) == 0ull) break;
+  while (WG ? wg_go : true) {
+    if (!WG && ballot(is_alive()) == 0ull) break;
     if (SKIP && wtest) march(std::integral_constant<bool, SKIP>{});
     else march(std::false_type{});
     nray = tau >= ert ? -1.0f : nray;   // the rays the march terminated
     // ---- next window ------------------------------------------------------------------------------------------------
     const unsigned long long live = ballot(is_alive());
-    if (live == 0ull) break;
-    if (!next_window(live)) break;
+    if (!WG && live == 0ull) break;
+    if (!next_window(live)) break;      // WG: false for the four waves together
   }
 
   // (kf counts the samples of a lane: without skipping every step it takes evaluates one; a terminated ray stopped at kf)
@@ -695,18 +779,28 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(PHONG ? (SK
   add_counts(dc, n_samples, n_rays, n_px, n_skipped, n_grads, n_slots, blk, n_loads, n_reads, n_tf);
 }
 
+#ifndef VX_LDS_S_WG   // steps per shared window (its geometry ends a lane's run long before)
+#define VX_LDS_S_WG 32   // 24 / 28 / 32 / 36 / 40 / 48 measured: 0.2070 / 0.2062 / 0.2040 / 0.2057 / 0.2075 / 0.2044 ms per frame (lane utilisation 0.939 ... 0.912)
+#endif
 inline void launch_dvr_lds(const VxParams& p, const DevVolume& v, const float4* tf, uint32_t tf_len, const MultiOut& mo,
-                           float weight, const TileMap& tm, hipStream_t stream, const uint32_t* order) {
+                           float weight, const TileMap& tm, hipStream_t stream, const uint32_t* order, bool shared_window = false) {
   const uint32_t groups = (tm.tiles_per_shard + 7u) / 8u;
   const dim3 grid(groups * 128u * (mo.count ? mo.count : 1u)), block(256);
   const bool skip = p.dvr_skip_empty && v.skip_bits;
   const bool phong = p.render_mode == VX_MODE_DVR_PHONG;
+  const bool u8 = v.bu_active != 0u;
+  // one window per workgroup: the plain DVR march on brickf32 in a launch of a multiple of 32 frames (render_dvr_lds, WG)
+  if (shared_window && !skip && !phong && !u8 && mo.count >= 32u && (mo.count & 31u) == 0u) {
+    const size_t lds_wg = (size_t)tf_len * sizeof(float4) + (size_t)LdsTile<false, true>::FLOATS * sizeof(float) + 32u * sizeof(int);
+    hipLaunchKernelGGL((render_dvr_lds<VX_LDS_S_WG, false, false, false, true>), grid, block, lds_wg, stream, p, v, tf, tf_len, mo,
+                       weight, tm, order);
+    return;
+  }
   const size_t tile_bytes = 4u * (size_t)(phong ? LdsTile<true>::FLOATS : LdsTile<false>::FLOATS) * sizeof(float);
   const size_t lds = (size_t)tf_len * sizeof(float4) + (skip ? (((size_t)v.skip_words + 3u) & ~(size_t)3u) * 4u : 0u) + tile_bytes;
 #define VX_LAUNCH_LDS(PH, SK, U)                                                                                          \
   hipLaunchKernelGGL((render_dvr_lds<(PH ? VX_LDS_S_PHONG : VX_LDS_S), PH, SK, U>), grid, block, lds, stream, p, v, tf, tf_len, \
                      mo, weight, tm, order)
-  const bool u8 = v.bu_active != 0u;
   if (phong) {
     if (skip) { if (u8) VX_LAUNCH_LDS(true, true, true); else VX_LAUNCH_LDS(true, true, false); }
     else      { if (u8) VX_LAUNCH_LDS(true, false, true); else VX_LAUNCH_LDS(true, false, false); }
