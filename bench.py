@@ -604,6 +604,10 @@ def main():
         }
         out = {
             "metric": "Gsamples/s raymarch @512^3 vol, 1080p; achieved HBM GB/s vs peak, 1/2/4/8 GPU",
+            "metric_note": "BASELINE.json's metric string, verbatim.  `value` is the Gsamples/s; the achieved HBM GB/s against the 8 TB/s "
+                           "peak is roofline.hbm_measured (rocprofv3 bytes of this command / this run's kernel time) -- the shipped "
+                           "kernel takes its taps from LDS windows and is bound by the vector ALUs, so the line's `roofline` is the "
+                           "VALU issue roofline (roofline.bound, roofline.frac_kind) and the HBM figure is reported beside it",
             "value": round(samples / elapsed / 1e9, 3),
             "value_cold": round(cold_samples / cold["elapsed"] / 1e9, 3) if cold else None,
             "unit": "Gsamples/s",
