@@ -570,7 +570,7 @@ def main():
                          "per sample inside the sample range, / 64 lanes; per-ray set-up, window placement and idle lanes are "
                          "NOT counted as necessary) per launch / kernel time, against 1024 SIMDs x 2.4 GHz / 2 clocks per instruction",
             "necessary_valu_per_launch": int(need), "necessary_model": NECESSARY_VALU,
-            "priced": {
+            "priced": None if not valu_bound else {
                 "frac": round((c.samples * NECESSARY_CLK["per_sample"] + c.tf_samples * NECESSARY_CLK["per_tf_sample"]) / 64.0 / launches
                               / (avg_kernel_s * N_SIMDS * NOMINAL_CLOCK_GHZ * 1e9), 4) if avg_kernel_s > 0 else None,
                 "necessary_clk_model": NECESSARY_CLK,

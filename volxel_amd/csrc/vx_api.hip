@@ -94,6 +94,8 @@ struct VxContext {
   size_t dc_waves = 0;
   uint32_t* order = nullptr;   // launch permutation of the DVR kernel (build_order), dc_waves/4 entries
   bool use_order = true;
+  int tex_checked_res[2] = {-1, -1};  // DevVolume::ray_flags: the resolution (pixel + 0.5) / res was last tried against its reciprocal form
+  bool tex_by_reciprocal[2] = {false, false};
   bool dvr_shared_window = false;    // VX_DVR_WG=1: one LDS window per workgroup in launches of a multiple of 32 frames (vx_dvr_lds.hpp, WG)
   int order_builds_left = 2;   // rebuild the order after the first frames that follow a change
   VxCounters base{};           // totals folded in when the record array is reallocated
@@ -1232,13 +1234,17 @@ static int prepare_render(VxContext* c, dim3& grid) {
     const float* vi = p.camera_view_inv;
     if (vi[3] == 0.0f && vi[7] == 0.0f && vi[11] == 0.0f && vi[15] == 1.0f) flags |= RAY_AFFINE_VIEW;
     for (int axis = 0; axis < 2; ++axis) {
-      const float res = (float)p.res[axis], y = c->dv.inv_res[axis];
-      bool same = true;
-      for (int px = 0; px < p.res[axis] && same; ++px) {
-        const float a = (float)px + 0.5f, q0 = a * y;
-        same = fmaf(fmaf(-res, q0, a), y, q0) == a / res;
+      if (c->tex_checked_res[axis] != p.res[axis]) {   // tried once per resolution, not per launch
+        const float res = (float)p.res[axis], y = c->dv.inv_res[axis];
+        bool same = true;
+        for (int px = 0; px < p.res[axis] && same; ++px) {
+          const float a = (float)px + 0.5f, q0 = a * y;
+          same = fmaf(fmaf(-res, q0, a), y, q0) == a / res;
+        }
+        c->tex_checked_res[axis] = p.res[axis];
+        c->tex_by_reciprocal[axis] = same;
       }
-      if (same) flags |= (axis == 0 ? RAY_TEX_BY_RECIPROCAL_X : RAY_TEX_BY_RECIPROCAL_Y);
+      if (c->tex_by_reciprocal[axis]) flags |= (axis == 0 ? RAY_TEX_BY_RECIPROCAL_X : RAY_TEX_BY_RECIPROCAL_Y);
     }
     if (getenv("VX_RAY_SHORTCUTS") && atoi(getenv("VX_RAY_SHORTCUTS")) == 0) flags = 0;   // diagnostic: the divisions themselves
     c->dv.ray_flags = flags;
