@@ -356,6 +356,12 @@ def main():
     ap.add_argument("--no-side-measurements", action="store_true",
                     help="skip the 1-frame-per-launch run and the L1 probes (profiling passes)")
     ap.add_argument("--force-gather", action="store_true", help="run the gather path with one rank too (testing)")
+    ap.add_argument("--rehearse-gloo", action="store_true",
+                    help="TEST MODE, not a measurement: run the N ranks of --gpus N on ONE device with the gloo backend (RCCL "
+                         "refuses several ranks on one GPU): everything of the N > 1 path -- tile dealing, balanced order, sharded "
+                         "contexts, launch plan, snapshot + all_gather + de-tile, the reductions of the line -- except RCCL itself; "
+                         "the collectives are staged through host memory.  The line says \"rehearsal\" and carries the sha256 of the "
+                         "gathered image (config.image_sha256: equal to a 1-rank --force-gather run of the same frames)")
     ap.add_argument("--no-balance", action="store_true",
                     help="N>1: keep the default round-robin dealing of the 64x64 tiles instead of the cost-balanced order")
     a = ap.parse_args()
@@ -382,14 +388,36 @@ def main():
         raise SystemExit(f"--gpus {a.gpus} but WORLD_SIZE={world}")
     if not torch.cuda.is_available():
         raise SystemExit(f"bench.py needs an MI355X: the HIP path has no CPU fallback (rank {rank} of {world})")
-    if torch.cuda.device_count() < (local + 1):
+    rehearse = bool(a.rehearse_gloo)
+    if torch.cuda.device_count() < (local + 1) and not rehearse:
         raise SystemExit(f"rank {rank} of {world}: no GPU {local} on this node ({torch.cuda.device_count()} visible)")
+    if rehearse:
+        local = local % max(torch.cuda.device_count(), 1)      # the ranks share the device(s) there are
     torch.cuda.set_device(local)
     use_dist = world > 1 or a.force_gather
     if use_dist:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29511")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local))
+        if rehearse:
+            dist.init_process_group("gloo", rank=rank, world_size=world)
+        else:
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local))
+
+    def barrier():
+        if rehearse:
+            dist.barrier()
+        else:
+            dist.barrier(device_ids=[local])
+
+    def all_reduce_(t, op):
+        """all_reduce of a small CUDA tensor (gloo rehearsal: through host memory)"""
+        if rehearse:
+            h = t.cpu()
+            dist.all_reduce(h, op=op)
+            t.copy_(h)
+        else:
+            dist.all_reduce(t, op=op)
+        return t
 
     r, msg, info = build_scene(a.width, a.height, a.volume, rank, world, local)
     if a.no_jitter:
@@ -440,7 +468,13 @@ def main():
             done = torch.cuda.Event()
             done.record(cs)
             state["copy_done"] = done
-            state["work"] = dist.all_gather_into_tensor(gathered, snap, async_op=True)
+            if rehearse:                      # gloo has no CUDA all_gather: through host memory, synchronously
+                host = snap.cpu()
+                out = torch.empty(world * host.numel(), dtype=host.dtype)
+                dist.all_gather_into_tensor(out, host)
+                gathered.copy_(out)
+            else:
+                state["work"] = dist.all_gather_into_tensor(gathered, snap, async_op=True)
             state["gathers"] += 1
 
     def fence():
@@ -451,7 +485,7 @@ def main():
             state["work"].wait()              # orders the current stream behind the collective (no host wait)
         torch.cuda.synchronize(); tt.append(time.perf_counter())
         if use_dist:
-            dist.barrier(device_ids=[local])  # returns when every rank has arrived (it synchronises its own stream)
+            barrier()                         # returns when every rank has arrived (it synchronises its own stream)
         tt.append(time.perf_counter())
         if os.environ.get("VX_BENCH_TRACE"):
             sys.stderr.write("fence: " + " ".join(f"{(b - a) * 1e3:.3f}" for a, b in zip(tt, tt[1:])) + " ms\n")
@@ -466,7 +500,7 @@ def main():
     if use_dist:
         # RCCL's first barrier sets the collective up (12 ms measured): here, not in the fence before the timed region,
         # where it would leave the device idle
-        dist.barrier(device_ids=[local])
+        barrier()
 
     def timed(first):
         """W untimed warm-up steps, then EXACTLY a.steps steps (x F accumulation frames) between two fences"""
@@ -481,7 +515,7 @@ def main():
         dt = time.perf_counter() - t0
         if use_dist:
             t = torch.tensor([dt], dtype=torch.float64, device="cuda")
-            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            all_reduce_(t, dist.ReduceOp.MAX)
             dt = float(t.item())
         return dt, r.counters()
 
@@ -519,19 +553,23 @@ def main():
         fixed_ms = (time.perf_counter() - tf0) * 1e3
         if use_dist:
             t = torch.tensor([fixed_ms], dtype=torch.float64, device="cuda")
-            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            all_reduce_(t, dist.ReduceOp.MAX)
             fixed_ms = float(t.item())
 
     samples, pixels = c.samples, c.pixels
     cold_samples = cold["samples"] if cold else 0
     if use_dist:
         s = torch.tensor([samples, pixels, cold_samples], dtype=torch.float64, device="cuda")
-        dist.all_reduce(s, op=dist.ReduceOp.SUM)
+        all_reduce_(s, dist.ReduceOp.SUM)
         samples, pixels, cold_samples = int(s[0].item()), int(s[1].item()), int(s[2].item())
+    image_sha = None
     if use_dist and state["gathers"]:
         # de-tile the last gathered framebuffer so that the image is materialised
         r.detile(gathered.data_ptr(), image.data_ptr())
         r.finish()
+        if rank == 0 and (rehearse or a.force_gather):
+            import hashlib
+            image_sha = hashlib.sha256(image.cpu().numpy().tobytes()).hexdigest()
 
     if rank == 0:
         name, cus, mem = r.device_info()
@@ -608,6 +646,8 @@ def main():
                            "peak is roofline.hbm_measured (rocprofv3 bytes of this command / this run's kernel time) -- the shipped "
                            "kernel takes its taps from LDS windows and is bound by the vector ALUs, so the line's `roofline` is the "
                            "VALU issue roofline (roofline.bound, roofline.frac_kind) and the HBM figure is reported beside it",
+            "rehearsal": ("gloo backend, the ranks share one device: a functional rehearsal of the N > 1 path, NOT a "
+                          "performance measurement") if rehearse else None,
             "value": round(samples / elapsed / 1e9, 3),
             "value_cold": round(cold_samples / cold["elapsed"] / 1e9, 3) if cold else None,
             "unit": "Gsamples/s",
@@ -632,6 +672,7 @@ def main():
                                 f"all_gather of the framebuffer every {a.gather_every} frames, overlapped)")
                                if use_dist else "1 GPU",
                 "gathers": n_gathers,
+                "image_sha256": image_sha,
                 "layout": LAYOUT[a.layout],
                 "frames_per_step": F, "frames_timed": frames_timed,
                 "samples_per_frame": int(samples // frames_timed),
@@ -706,7 +747,7 @@ def main():
         real_stdout.write(json.dumps(out) + "\n")
         real_stdout.flush()
     if use_dist:
-        dist.barrier(device_ids=[local])
+        barrier()
         dist.destroy_process_group()
 
 

@@ -1458,3 +1458,35 @@ def test_context_lifecycle_releases_device_memory(oracle):
     gc.collect(); torch.cuda.synchronize()
     free1 = torch.cuda.mem_get_info()[0]
     assert free0 - free1 < 64 << 20, (free0 - free1) / 2 ** 20
+
+
+def test_bench_two_ranks_rehearsal_gathers_the_one_rank_image():
+    """bench.py's N > 1 path end to end on the one GPU there is: `--gpus 2 --rehearse-gloo` starts two ranks (child processes
+    of bench.py's own launcher) that share the device and use the gloo backend -- tile dealing in the balanced order, sharded
+    contexts, 64-frame launches, snapshot + all_gather + de-tile, the reductions of the JSON line: everything but RCCL.  The
+    gathered image of its 96 accumulation frames must be the image a single rank gathers (`--force-gather`) bit for bit, the
+    sample counts must agree, and the line must say n_gpus 2 and call itself a rehearsal."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    lean = ["--steps", "2", "--warmup", "1", "--no-cpu-baseline", "--no-mode-variants", "--no-skip-variant",
+            "--no-side-measurements"]
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+
+    def run(extra):
+        p = subprocess.run([sys.executable, os.path.join(root, "bench.py"), *extra, *lean], env=env, capture_output=True,
+                           text=True, timeout=600)
+        assert p.returncode == 0, p.stderr[-2000:]
+        lines = [ln for ln in p.stdout.splitlines() if ln.startswith("{")]
+        assert len(lines) == 1, p.stdout[-500:]
+        return json.loads(lines[0])
+
+    one = run(["--gpus", "1", "--force-gather"])
+    two = run(["--gpus", "2", "--rehearse-gloo"])
+    assert one["n_gpus"] == 1 and two["n_gpus"] == 2 and two["rehearsal"] and not one["rehearsal"]
+    assert one["config"]["image_sha256"] and one["config"]["image_sha256"] == two["config"]["image_sha256"]
+    assert one["config"]["samples_per_frame"] == two["config"]["samples_per_frame"]
+    assert two["config"]["frames_per_launch"] == 64 and one["config"]["frames_per_launch"] == 32
+    assert two["config"]["gathers"] >= 2 and "image-tiles x2" in two["config"]["parallelism"]
+    assert two["cpu_baseline"] is None and two["scaling"] == "strong"
