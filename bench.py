@@ -574,8 +574,11 @@ def main():
     if rank == 0:
         name, cus, mem = r.device_info()
         launches = max(c.launches, 1)
-        multi = c.max_launch_frames > 1      # multi-frame launches write results; the blend kernel is apart
-        px_bytes = BYTES_PER_PIXEL_RESULT if multi else BYTES_PER_PIXEL_BLEND
+        multi = c.max_launch_frames > 1      # multi-frame launches write results; the blend kernel is apart ...
+        fused = multi and c.merge_ms == 0.0  # ... unless the render kernel applied the running mean itself (MultiOut::fuse, round 4):
+                                             # then a launch reads and writes the accumulator ONCE per pixel, whatever its frames
+        px_bytes = (BYTES_PER_PIXEL_BLEND / max(int(c.max_launch_frames), 1)) if fused else \
+                   (BYTES_PER_PIXEL_RESULT if multi else BYTES_PER_PIXEL_BLEND)
         alg_bytes_launch = (c.samples * BYTES_PER_SAMPLE + c.pixels * px_bytes) / launches
         avg_kernel_s = c.kernel_ms / launches / 1e3
         achieved = alg_bytes_launch / avg_kernel_s / 1e9 if avg_kernel_s > 0 else 0.0
@@ -627,15 +630,20 @@ def main():
             "avg_kernel_ms": round(c.kernel_ms / launches, 4), "launches": int(c.launches), "frames": int(c.frames),
             "frames_per_launch": fpl, "min_frames_per_launch": int(c.min_launch_frames),
             "algorithmic_bytes_per_launch": int(alg_bytes_launch),
-            "algorithmic_model": f"{int(BYTES_PER_SAMPLE)} B/sample + {int(px_bytes)} B/pixel/frame "
-                                 + ("(the result this kernel writes; the blend's 32 B/pixel/frame are in `blend`)"
-                                    if multi else "(accumulator read + write in the same kernel)"),
+            "algorithmic_model": f"{int(BYTES_PER_SAMPLE)} B/sample + "
+                                 + ("32 B/pixel/launch (the running mean of the launch's frames is applied in the render kernel: "
+                                    "one accumulator read + write per pixel and launch)" if fused else
+                                    (f"{int(px_bytes)} B/pixel/frame (the result this kernel writes; the blend's 32 B/pixel/frame are in `blend`)"
+                                     if multi else f"{int(px_bytes)} B/pixel/frame (accumulator read + write in the same kernel)")),
             "rank0_gsamples_per_s_kernel_only": round(c.samples / (c.kernel_ms / 1e3) / 1e9, 3) if c.kernel_ms else None,
             "hbm_measured": ({"gbs": round(prof["traffic"] / avg_kernel_s / 1e9, 1),
                               "frac": round(prof["traffic"] / avg_kernel_s / 1e9 / HBM_PEAK_GBS, 4),
                               "note": "rocprofv3 bytes of the profiled run of this command / this run's kernel time"}
                              if prof.get("traffic") and avg_kernel_s > 0 else None),
-            "blend": {"kernel": "vx::merge_results", "ms_per_launch": round(c.merge_ms / launches, 4),
+            "blend": {"fused": True, "note": "no blend kernel ran: the render kernel folds the launch's frames into the accumulator in "
+                                              "frame order itself (a wave holds every frame of its pixels in launches of exactly 32 / "
+                                              "64 frames; VX_DVR_FUSE=0 restores per-frame result slabs + vx::merge_results)"} if fused else
+                     {"kernel": "vx::merge_results", "ms_per_launch": round(c.merge_ms / launches, 4),
                       "algorithmic_bytes_per_launch": int(c.pixels / launches * (BYTES_PER_PIXEL_RESULT + BYTES_PER_PIXEL_BLEND / max(fpl, 1))),
                       "note": "reads the per-frame results, applies fragment.frag:158 in frame order, one accumulator "
                               "read + write per launch"} if multi else None,

@@ -1315,6 +1315,43 @@ def test_volume_beyond_the_cellquad_index_range_is_refused(oracle):
     r.close()
 
 
+@pytest.mark.parametrize("mode", ["dvr", "dvr_phong"])
+def test_running_mean_in_the_render_kernel_is_bit_identical(oracle, monkeypatch, mode):
+    """MultiOut::fuse (round 4): in a launch of exactly 32 or 64 frames a wave of the LDS-window kernel holds every frame of its
+    2 (or 1) pixels and folds their results into the accumulator itself, in frame order, with the fma of fragment.frag:158 --
+    no per-frame result slabs, no blend kernel.  Against VX_DVR_FUSE=0 (result slabs + merge_results) and against the same
+    frames one by one: the same bits, with and without zero weights in the launch (the first frames of an accumulation
+    carry weight 0: merge_results drops the previous value there), on a ragged image, for 32 and 64 frames in flight and a
+    request that ends in a partial launch (which takes the unfused path)."""
+    from tests.common import benchmark_tf, BENCH_CAM, small_noise
+    from volxel_amd import Volxel3DRenderer
+    vox, sp = small_noise(64, seed=13)
+    g = oracle.BrickGrid(vox, sp)
+    tf, L = benchmark_tf()
+    res = {}
+    for key, fuse, fpl in (("serial", "1", 1), ("merge32", "0", 32), ("fused32", "1", 32), ("fused64", "1", 64)):
+        monkeypatch.setenv("VX_DVR_FUSE", fuse)
+        r = Volxel3DRenderer(203, 131)
+        r.setup_from_grid(g)
+        r.change_transfer_func(tf, L)
+        r.settings.render_mode, r.settings.dvr_jitter, r.settings.dvr_skip_empty = mode, True, False
+        r.settings.sample_range = (0.05, 1.0)
+        r.camera.pos = np.asarray(BENCH_CAM["cam_pos"], dtype=np.float64)
+        r.camera.view = np.asarray(BENCH_CAM["look_at"], dtype=np.float64)
+        r.reset_counters()
+        r.render(frames=2)                                  # the two frames that build the launch order
+        r.render(frames=64 + 64 + 7, in_flight=fpl)         # frames 2 .. 136: launches with zero weights, without, and a partial one
+        c = r.counters()
+        res[key] = (r.read_accum(), c.samples, c.tf_samples, c.merge_ms, c.max_launch_frames)
+        r.close()
+    assert res["merge32"][3] > 0.0 and res["merge32"][4] == 32          # the blend kernel ran there ...
+    assert res["fused64"][4] == 64
+    for key in ("merge32", "fused32", "fused64"):
+        assert np.array_equal(res[key][0], res["serial"][0]) and res[key][1:3] == res["serial"][1:3], key
+    # ... and only for the partial launch here (7 frames): a fraction of the time
+    assert 0.0 < res["fused32"][3] < 0.5 * res["merge32"][3]
+
+
 def test_shared_window_kernel_is_bit_identical(oracle, monkeypatch):
     """VX_DVR_WG=1 (vx_dvr_lds.hpp, WG): in launches of a multiple of 32 frames the four waves of a workgroup take the same 8
     pixels (8 frames each) and march through ONE window four times the volume, placed through an exchange in LDS and two

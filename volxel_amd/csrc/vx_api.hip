@@ -96,6 +96,7 @@ struct VxContext {
   bool use_order = true;
   int tex_checked_res[2] = {-1, -1};  // DevVolume::ray_flags: the resolution (pixel + 0.5) / res was last tried against its reciprocal form
   bool tex_by_reciprocal[2] = {false, false};
+  bool dvr_fuse = true;              // VX_DVR_FUSE=0: multi-frame DVR launches write per-frame results and merge_results blends them
   bool dvr_shared_window = false;    // VX_DVR_WG=1: one LDS window per workgroup in launches of a multiple of 32 frames (vx_dvr_lds.hpp, WG)
   int order_builds_left = 2;   // rebuild the order after the first frames that follow a change
   VxCounters base{};           // totals folded in when the record array is reallocated
@@ -612,6 +613,8 @@ int vx_create(int device_id, VxContext** out) {
   if (pk && !strcmp(pk, "events")) c->paths_variant = 3;     // wave-persistent, event-batched (vx_events.hpp): measured slower
   const char* dpe = getenv("VX_DVR_DP");
   if (dpe) c->dp_env = atoi(dpe);
+  const char* fu = getenv("VX_DVR_FUSE");
+  if (fu) c->dvr_fuse = atoi(fu) != 0;
   const char* wg = getenv("VX_DVR_WG");
   if (wg) c->dvr_shared_window = atoi(wg) != 0;
   const char* o = getenv("VX_DVR_ORDER");
@@ -1433,6 +1436,18 @@ int vx_render_frames(VxContext* c, uint32_t first_frame, uint32_t count, const f
         ma.result[i] = c->pipes[i].result;
         ma.weight[i] = weights[done + i];
       }
+      // the LDS-window kernel applies the running mean itself when one wave holds every frame of its pixels: a launch of
+      // exactly 32 or 64 frames (MultiOut::fuse; VX_DVR_FUSE=0 keeps the result slabs and the blend kernel)
+      const bool fused = tuned_lds && c->dvr_fuse && !c->dvr_shared_window && (n == 32u || n == 64u);
+      if (fused) {
+        bool zero = false;
+        for (uint32_t i = 0; i < n; ++i) {
+          mo.weight[i] = ma.weight[i];
+          zero = zero || ma.weight[i] == 0.0f;
+        }
+        mo.fuse = zero ? 2u : 1u;
+        mo.accum = c->slab;
+      }
       EventPair e2;
       if ((rc = take_events(c, e2))) return rc;
       VX_HIP(c, hipEventRecord(e2.a, c->stream));
@@ -1447,7 +1462,7 @@ int vx_render_frames(VxContext* c, uint32_t first_frame, uint32_t count, const f
       le = hipGetLastError();
       VX_HIP(c, hipEventRecord(e2.b, c->stream));   // the render kernel alone; the blend is outside
       c->pending_events.push_back(e2);
-      if (le == hipSuccess) {
+      if (le == hipSuccess && !fused) {
         EventPair e3;
         if ((rc = take_events(c, e3))) return rc;
         e3.merge = true;

@@ -52,8 +52,8 @@ VXD DvrRay dvr_setup(const VxParams& p, const DevVolume& v, int px, int py, uint
 }
 
 // write-back shared by the tuned DVR kernels: gain, background, sanitize, running mean
-VXD void dvr_store(const VxParams& p, const DevVolume& dv, const DvrRay& r, float Cx, float Cy, float Cz, float T,
-                   float weight, float4* __restrict__ slab, uint32_t si) {
+// the radiance of a DVR ray: gain, background, sanitize (the value dvr_store blends)
+VXD V3 dvr_radiance(const VxParams& p, const DevVolume& dv, const DvrRay& r, float Cx, float Cy, float Cz, float T) {
   float Lx = Cx * p.dvr_gain[0], Ly = Cy * p.dvr_gain[1], Lz = Cz * p.dvr_gain[2];
   if (p.show_environment > 0 && T > 0.0f) {
     V3 env = lookup_environment(p, dv, r.wdir);
@@ -61,7 +61,12 @@ VXD void dvr_store(const VxParams& p, const DevVolume& dv, const DvrRay& r, floa
     Ly = fma_(T, env.y, Ly);
     Lz = fma_(T, env.z, Lz);
   }
-  Lx = sanitize1(Lx); Ly = sanitize1(Ly); Lz = sanitize1(Lz);
+  return v3(sanitize1(Lx), sanitize1(Ly), sanitize1(Lz));
+}
+VXD void dvr_store(const VxParams& p, const DevVolume& dv, const DvrRay& r, float Cx, float Cy, float Cz, float T,
+                   float weight, float4* __restrict__ slab, uint32_t si) {
+  const V3 L = dvr_radiance(p, dv, r, Cx, Cy, Cz, T);
+  const float Lx = L.x, Ly = L.y, Lz = L.z;
   float4 prev = make_float4(0.f, 0.f, 0.f, 0.f);
   if (weight != 0.0f) prev = slab[si];
   float4 o;

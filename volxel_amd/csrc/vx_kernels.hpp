@@ -142,6 +142,15 @@ struct MultiOut {
   DevCounters* dc[MERGE_MAX];
   uint32_t frame[MERGE_MAX];
   uint32_t count;
+  // Round 4, behind the fields lane_frame_slot addresses (their offsets do not move): the running mean applied IN the render
+  // kernel.  fuse != 0 (the launcher sets it for a launch of exactly 32 or 64 frames of the LDS-window DVR kernel): a wave
+  // holds every frame of its 2 (or 1) pixels, so it folds their results in frame order into `accum` itself -- fragment.frag:158
+  // with weight[k] for frame slot k, exactly what merge_results does -- and neither the per-frame result slabs nor the blend
+  // kernel are touched.  fuse == 2: some weight of the launch is 0 (the previous value is then dropped: merge_results'
+  // `w != 0 ? acc : 0`), the fold tests each weight; fuse == 1: none is.
+  uint32_t fuse;
+  float4* accum;
+  float weight[MERGE_MAX];
 };
 
 // launch slot p of a multi-frame launch -> (frame slot, block slot).  Default: frame slots of one block are consecutive
