@@ -1315,14 +1315,15 @@ def test_volume_beyond_the_cellquad_index_range_is_refused(oracle):
     r.close()
 
 
-@pytest.mark.parametrize("mode", ["dvr", "dvr_phong"])
+@pytest.mark.parametrize("mode", ["dvr", "dvr_phong", "default", "no_dda", "raymarch"])
 def test_running_mean_in_the_render_kernel_is_bit_identical(oracle, monkeypatch, mode):
     """MultiOut::fuse (round 4): in a launch of exactly 32 or 64 frames a wave of the LDS-window kernel holds every frame of its
     2 (or 1) pixels and folds their results into the accumulator itself, in frame order, with the fma of fragment.frag:158 --
     no per-frame result slabs, no blend kernel.  Against VX_DVR_FUSE=0 (result slabs + merge_results) and against the same
     frames one by one: the same bits, with and without zero weights in the launch (the first frames of an accumulation
     carry weight 0: merge_results drops the previous value there), on a ragged image, for 32 and 64 frames in flight and a
-    request that ends in a partial launch (which takes the unfused path)."""
+    request that ends in a partial launch (which takes the unfused path).  The reference's three modes do the same in
+    render_generic for launches of exactly 32 frames (2 pixels x 32 frames per wave, the workgroup's beam unchanged)."""
     from tests.common import benchmark_tf, BENCH_CAM, small_noise
     from volxel_amd import Volxel3DRenderer
     vox, sp = small_noise(64, seed=13)
@@ -1335,7 +1336,7 @@ def test_running_mean_in_the_render_kernel_is_bit_identical(oracle, monkeypatch,
         r.setup_from_grid(g)
         r.change_transfer_func(tf, L)
         r.settings.render_mode, r.settings.dvr_jitter, r.settings.dvr_skip_empty = mode, True, False
-        r.settings.sample_range = (0.05, 1.0)
+        r.settings.sample_range, r.settings.bounces, r.settings.max_samples = (0.05, 1.0), 2, 1 << 20
         r.camera.pos = np.asarray(BENCH_CAM["cam_pos"], dtype=np.float64)
         r.camera.view = np.asarray(BENCH_CAM["look_at"], dtype=np.float64)
         r.reset_counters()

@@ -529,6 +529,7 @@ static void launch_generic_mode(VxContext* c, const MultiOut& mo, float weight, 
     return;
   }
   size_t lds = c->tf_len <= TF_LDS_MAX ? (size_t)c->tf_len * sizeof(float4) : 0;
+  if (mo.fuse) lds += 4u * 320u * sizeof(float);   // fold_frames' scratch, one per wave (generic_fusable)
   // (bounces < 1: fragment.frag:86-101 still traces the primary segment and one light sample before it tests the
   // count; render_paths loops on `n_paths < bounces` and would leave the slab unwritten -- render_generic serves it)
   if (c->paths_variant == 1 && !c->params.debug_hits && c->params.render_mode <= VX_MODE_RAYMARCH && c->params.bounces >= 1) {
@@ -546,6 +547,16 @@ static void launch_generic_mode(VxContext* c, const MultiOut& mo, float weight, 
     case VX_MODE_DVR: launch_generic<VX_MODE_DVR>(c, mo, weight, grid, lds, stream); break;
     default: launch_generic<VX_MODE_DVR_PHONG>(c, mo, weight, grid, lds, stream); break;
   }
+}
+
+// will launch_generic_mode run render_generic<MODE <= RAYMARCH> for this context?  (Only that kernel applies the running mean of
+// a 32-frame launch itself, MultiOut::fuse; the re-packed and event-batched path kernels and the DVR modes on the generic
+// kernel keep the result slabs and merge_results.)
+static bool generic_fusable(const VxContext* c, const MultiOut& mo) {
+  if (c->params.render_mode > VX_MODE_RAYMARCH) return false;
+  if (events_possible(c, mo)) return false;
+  if (c->paths_variant == 1 && !c->params.debug_hits && c->params.bounces >= 1) return false;
+  return true;
 }
 
 extern "C" {
@@ -1438,7 +1449,9 @@ int vx_render_frames(VxContext* c, uint32_t first_frame, uint32_t count, const f
       }
       // the LDS-window kernel applies the running mean itself when one wave holds every frame of its pixels: a launch of
       // exactly 32 or 64 frames (MultiOut::fuse; VX_DVR_FUSE=0 keeps the result slabs and the blend kernel)
-      const bool fused = tuned_lds && c->dvr_fuse && !c->dvr_shared_window && (n == 32u || n == 64u);
+      const bool fused = c->dvr_fuse &&
+                         ((tuned_lds && !c->dvr_shared_window && (n == 32u || n == 64u)) ||
+                          (!is_tuned(c) && n == 32u && generic_fusable(c, mo)));
       if (fused) {
         bool zero = false;
         for (uint32_t i = 0; i < n; ++i) {

@@ -782,50 +782,9 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(PHONG ? (SK
     // 0 .. 3 npx - 1 then each fold one colour channel of one pixel through the frame slots in order:
     // acc = fma(1 - w, r, w * (w != 0 ? acc : 0)) -- merge_results, operation for operation, on the value dvr_store would
     // have written to the frame's result slab (fma(1, L, 0 * 0)).
-    const uint32_t sh = mo.count == 64u ? 6u : 5u, psh = 6u - sh, npx = 1u << psh, nfr = 1u << sh;
     V3 L = v3(0.f, 0.f, 0.f);
     if (in_image) L = dvr_radiance(p, v, r, Cx, Cy, Cz, T);
-    float* const fold = tile;                       // 64 x 3 results, then nfr x {w, 1 - w}
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-    __builtin_amdgcn_wave_barrier();
-    fold[lane * 3u + 0u] = fma_(1.0f, L.x, 0.0f);
-    fold[lane * 3u + 1u] = fma_(1.0f, L.y, 0.0f);
-    fold[lane * 3u + 2u] = fma_(1.0f, L.z, 0.0f);
-    if (lane < nfr) {
-      typedef const char __attribute__((address_space(4)))* KPtr;
-      struct KArgs { VxParams p; DevVolume v; const float4* tf; uint32_t tf_len; MultiOut mo; };
-      const KPtr ka = (KPtr)__builtin_amdgcn_kernarg_segment_ptr() + offsetof(KArgs, mo) + offsetof(MultiOut, weight);
-      const float w = ((const float __attribute__((address_space(4)))*)ka)[lane];
-      fold[192u + 2u * lane] = w;
-      fold[193u + 2u * lane] = 1.0f - w;
-    }
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-    __builtin_amdgcn_wave_barrier();
-    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-    const unsigned long long inimg = ballot(in_image);
-    const uint32_t fp = lane / 3u, ch = lane - 3u * fp;                     // pixel and channel this lane folds
-    const uint32_t si_p = (uint32_t)__builtin_amdgcn_readlane((int)si, 0), si_q = (uint32_t)__builtin_amdgcn_readlane((int)si, 1);
-    const bool folds = lane < 3u * npx && ((inimg >> fp) & 1ull);
-    if (folds) {
-      float* const cell = reinterpret_cast<float*>(mo.accum + (fp == 0u ? si_p : si_q)) + ch;
-      float acc = *cell;
-      const float* rp = fold + fp * 3u + ch;
-      if (fuse == 1u) {                                                    // no weight of the launch is 0
-#pragma unroll 4
-        for (uint32_t k = 0; k < nfr; ++k) {
-          const float w = fold[192u + 2u * k], omw = fold[193u + 2u * k];
-          acc = fma_(omw, rp[(k << psh) * 3u], w * acc);
-        }
-      } else {
-        for (uint32_t k = 0; k < nfr; ++k) {
-          const float w = fold[192u + 2u * k], omw = fold[193u + 2u * k];
-          const float prev = w != 0.0f ? acc : 0.0f;
-          acc = fma_(omw, rp[(k << psh) * 3u], w * prev);
-        }
-      }
-      *cell = acc;
-      if (ch == 0u) reinterpret_cast<float*>(mo.accum + (fp == 0u ? si_p : si_q))[3] = 1.0f;
-    }
+    fold_frames(tile, lane, L, in_image, si, mo.accum, fuse, mo.count == 64u ? 6u : 5u);
   } else if (in_image) dvr_store(p, v, r, Cx, Cy, Cz, T, weight, slab, si);
   const uint32_t n_px = (uint32_t)__builtin_popcountll(ballot(in_image));
   add_counts(dc, n_samples, n_rays, n_px, n_skipped, n_grads, n_slots, blk, n_loads, n_reads, n_tf);

@@ -204,6 +204,56 @@ VXD float4* lane_frame_slot(uint32_t my_fslot, uint32_t& frame) {
   return ((float4* const __attribute__((address_space(4)))*)(ka + offsetof(MultiOut, out)))[my_fslot];
 }
 
+// MultiOut::fuse: the running mean of a launch's frames applied by the wave that holds every frame of its pixels (lane l =
+// frame slot l >> psh of pixel l & (npx - 1); sh = 5: 2 pixels x 32 frames, sh = 6: 1 pixel x 64 frames).  The wave parks its
+// 64 results and the launch's weights {w, 1 - w} in `fold` (320 floats of wave-private LDS), then lanes 0 .. 3 npx - 1 each
+// fold one colour channel of one pixel through the frame slots in order: acc = fma(1 - w, r, w * (w != 0 ? acc : 0)) --
+// merge_results, operation for operation, on the value the unfused path writes to the frame's result slab
+// (fma(1 - 0, L, 0 * 0)).  fuse == 1: no weight of the launch is 0, the test on w is compiled out of the loop.
+VXD void fold_frames(float* fold, uint32_t lane, V3 L, bool in_image, uint32_t si, float4* accum, uint32_t fuse, uint32_t sh) {
+  const uint32_t psh = 6u - sh, npx = 1u << psh, nfr = 1u << sh;
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");   // whatever the wave read from this LDS before is done
+  __builtin_amdgcn_wave_barrier();
+  fold[lane * 3u + 0u] = fma_(1.0f, L.x, 0.0f);
+  fold[lane * 3u + 1u] = fma_(1.0f, L.y, 0.0f);
+  fold[lane * 3u + 2u] = fma_(1.0f, L.z, 0.0f);
+  if (lane < nfr) {
+    typedef const char __attribute__((address_space(4)))* KPtr;
+    struct KArgs { VxParams p; DevVolume v; const float4* tf; uint32_t tf_len; MultiOut mo; };
+    const KPtr ka = (KPtr)__builtin_amdgcn_kernarg_segment_ptr() + offsetof(KArgs, mo) + offsetof(MultiOut, weight);
+    const float w = ((const float __attribute__((address_space(4)))*)ka)[lane];
+    fold[192u + 2u * lane] = w;
+    fold[193u + 2u * lane] = 1.0f - w;
+  }
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+  const unsigned long long inimg = ballot(in_image);
+  const uint32_t fp = lane / 3u, ch = lane - 3u * fp;                     // pixel and channel this lane folds
+  const uint32_t si_p = (uint32_t)__builtin_amdgcn_readlane((int)si, 0), si_q = (uint32_t)__builtin_amdgcn_readlane((int)si, 1);
+  const bool folds = lane < 3u * npx && ((inimg >> fp) & 1ull);
+  if (folds) {
+    float* const px4 = reinterpret_cast<float*>(accum + (fp == 0u ? si_p : si_q));
+    float acc = px4[ch];
+    const float* rp = fold + fp * 3u + ch;
+    if (fuse == 1u) {
+#pragma unroll 4
+      for (uint32_t k = 0; k < nfr; ++k) {
+        const float w = fold[192u + 2u * k], omw = fold[193u + 2u * k];
+        acc = fma_(omw, rp[(k << psh) * 3u], w * acc);
+      }
+    } else {
+      for (uint32_t k = 0; k < nfr; ++k) {
+        const float w = fold[192u + 2u * k], omw = fold[193u + 2u * k];
+        const float prev = w != 0.0f ? acc : 0.0f;
+        acc = fma_(omw, rp[(k << psh) * 3u], w * prev);
+      }
+    }
+    px4[ch] = acc;
+    if (ch == 0u) px4[3] = 1.0f;
+  }
+}
+
 // vx_create's check of lane_frame_slot: a kernel with the render kernels' argument list reads every frame slot through the
 // kernel-argument segment and compares with the by-value struct; *bad counts the slots that differ (0 unless the
 // compiler's argument layout ever stops matching struct KArgs)
@@ -276,7 +326,17 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(generic_min
   // Path-traced modes in a multi-frame launch: lanes = pixels x frames (frame_group above), 8 pixels x 8 frames per wave.
   // The free-flight samples of one wave then fall along a beam 8 pixels wide instead of 64, and the vector L1 -- whose
   // misses in flight bound these modes -- serves more of them: no_dda 0.684 -> 0.622 ms per frame.
-  if (MODE <= VX_MODE_RAYMARCH && mo.count > 1u) {   // wave uniform
+  const uint32_t fuse = (MODE <= VX_MODE_RAYMARCH) ? mo.fuse : 0u;   // wave uniform; the launcher sets it for 32-frame launches only
+  if (fuse != 0u) {
+    // the running mean applied here (MultiOut::fuse): the workgroup at slot r of the 32 takes wave tile r >> 3 of its block
+    // position and pixel octet r & 7 as below, but each of its waves takes 2 of the 8 pixels for ALL 32 frames -- the
+    // workgroup's beam is the same 8 pixels x 32 frames, and a wave holds every frame of its pixels
+    const uint32_t r = fslot & 31u, w = threadIdx.x >> 6;
+    wt = sub * 4u + (r >> 3);
+    const uint32_t my_fslot = (fslot - r) + (lane >> 1);
+    lane = ((r & 7u) << 3) + 2u * w + (lane & 1u);
+    slab = lane_frame_slot(my_fslot, my_frame);
+  } else if (MODE <= VX_MODE_RAYMARCH && mo.count > 1u) {   // wave uniform
     uint32_t base;
     const uint32_t sh = frame_group<3>(fslot, mo.count, base);
     if (sh != 0u) {
@@ -299,6 +359,19 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(generic_min
   uint32_t si;
   bool active = wave_pixel(tm, lt, wt, lane, px, py, si);
   Counts c{0, 0, 0, 0, 0};
+  if (fuse != 0u) {
+    V3 L = v3(0.f, 0.f, 0.f);
+    if (active) {
+      Frame<LAYOUT> f{p, v, tf, c};
+      const float4 r = f.template shade_pixel<MODE>(px, py, my_frame);
+      L = v3(r.x, r.y, r.z);
+    }
+    // wave-private scratch behind the transfer function (launch_generic adds it to the LDS size of a fused launch)
+    float* const fold = reinterpret_cast<float*>(tf_lds + (tf_len <= TF_LDS_MAX ? tf_len : 0u)) + (threadIdx.x >> 6) * 320u;
+    fold_frames(fold, threadIdx.x & 63u, L, active, si, mo.accum, fuse, 5u);
+    flush_counts(dc, c, active ? 1u : 0u, blk);
+    return;
+  }
   if (active) {
     Frame<LAYOUT> f{p, v, tf, c};
     float4 r = f.template shade_pixel<MODE>(px, py, my_frame);
