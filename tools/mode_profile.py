@@ -13,9 +13,9 @@ r.render(frames=2, rebind=False); r.finish()
 import time
 t0 = time.perf_counter()
 while time.perf_counter() - t0 < 0.15:          # bring the device to its sustained clock
-    r.render(frames=16, rebind=False, in_flight=16); r.finish()
+    r.render(frames=32, rebind=False, in_flight=32); r.finish()
 r.restart_rendering(); r.bind_uniforms()
 r.render(frames=2, rebind=False); r.finish(); r.reset_counters()
-r.render(frames=32, rebind=False, in_flight=16); r.finish()
+r.render(frames=64, rebind=False, in_flight=32); r.finish()
 c = r.counters()
 print(mode, "ms/frame", c.kernel_ms / c.frames, "Msamples", c.samples / c.frames / 1e6, "pixels/frame", c.pixels / c.frames, "launches", c.launches, "frames", c.frames)

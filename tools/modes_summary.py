@@ -9,7 +9,7 @@ from collections import defaultdict
 
 root = sys.argv[1]
 print(f"# rocprofv3 --pmc (two passes per mode, counters only) of the reference render modes on config 3, 1080p, default")
-print(f"# environment map, bounces 1, 16 frames per launch (tools/modes_pmc.sh, tools/mode_profile.py); values of the")
+print(f"# environment map, bounces 1, 32 frames per launch (tools/modes_pmc.sh, tools/mode_profile.py); values of the")
 print(f"# largest launch; ms per frame from the library's HIP events in the same runs")
 json_out = None
 if "--json" in sys.argv:
@@ -17,7 +17,7 @@ if "--json" in sys.argv:
     import json
     db = {"_note": "lane utilisation of the reference render modes on the bench scene (config 3: 512^3, 1920x1080, bounces 1, default "
                    "environment map): SQ_THREAD_CYCLES_VALU / (64 x SQ_ACTIVE_INST_VALU) of the rocprofv3 PMC passes of tools/modes_pmc.sh "
-                   "(16 frames per launch); bench.py copies these into config.other_modes when the scene matches (source named per entry)"}
+                   "(32 frames per launch: the running mean is applied in the kernel, 2 pixels x 32 frames per wave); bench.py copies these into config.other_modes when the scene matches (source named per entry)"}
     try:
         old_db = json.load(open(json_out))
     except Exception:
