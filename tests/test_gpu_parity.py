@@ -1330,6 +1330,7 @@ def test_running_mean_in_the_render_kernel_is_bit_identical(oracle, monkeypatch,
     g = oracle.BrickGrid(vox, sp)
     tf, L = benchmark_tf()
     res = {}
+    monkeypatch.setenv("VX_DVR_WG", "0")     # (the shared-window kernel keeps the blend kernel: not what is under test here)
     for key, fuse, fpl in (("serial", "1", 1), ("merge32", "0", 32), ("fused32", "1", 32), ("fused64", "1", 64)):
         monkeypatch.setenv("VX_DVR_FUSE", fuse)
         r = Volxel3DRenderer(203, 131)
