@@ -257,15 +257,20 @@ def mode_record(mode, c, a):
                                           "staged once (vx_dvr_lds.hpp), so the model exceeds what the HBM pins carry: "
                                           "not a roofline fraction, see the top-level roofline for the limiter"}
                            if gbs > HBM_PEAK_GBS else {})},
-           "lane_utilisation": (round(c.samples / c.lane_slots, 4) if c.lane_slots else None),
-           "lane_utilisation_source": "counted by the kernel (samples / lane slots)" if c.lane_slots else None}
+           "lane_utilisation": (round((c.active_lane_slots or c.samples) / c.lane_slots, 4) if c.lane_slots else None),
+           "lane_utilisation_source": (("counted by the kernel: march-loop trips of the lanes / 64 x the trips of each wave's slowest lane "
+                                        "(primary + shadow segment; exact at bounces 1)") if c.active_lane_slots else
+                                       "counted by the kernel (samples / lane slots of the march)") if c.lane_slots else None}
     try:
         prof = json.load(open(os.path.join(ROOT, "profiles", "modes.json")))
         e = prof.get(mode)
-        if e and (e["width"], e["height"], e["volume"]) == (a.width, a.height, a.volume) and rec["lane_utilisation"] is None:
-            rec["lane_utilisation"] = e["lane_utilisation"]
-            rec["lane_utilisation_source"] = e["source"]
-            for k in ("hbm_bytes_per_frame", "l1_hit", "l2_hit"):
+        if e and (e["width"], e["height"], e["volume"]) == (a.width, a.height, a.volume):
+            # the committed PMC profile of this scene beside the live count: active lanes over ALL issued vector instructions
+            rec["lane_utilisation_pmc"] = e["lane_utilisation"]
+            rec["lane_utilisation_pmc_source"] = e["source"]
+            if rec["lane_utilisation"] is None:
+                rec["lane_utilisation"], rec["lane_utilisation_source"] = e["lane_utilisation"], e["source"]
+            for k in ("hbm_bytes_per_frame", "l1_hit", "l2_hit", "valu_issue_of_clocks"):
                 if k in e:
                     rec[k] = e[k]
     except Exception:

@@ -673,6 +673,10 @@ VXD float sanitize1(float x) { return (x != x || __builtin_isinf(x)) ? 0.0f : x;
 // per-wave work counters, flushed with one atomic per wave
 struct Counts {
   uint32_t samples, rays, skips, grads, tf;
+  // march-loop trips of this lane in the collision searches (primary segments) and in the transmittance estimates (shadow
+  // segments) of trace_path: a few instructions per SEGMENT, none per trip (differences of samples / skips around the
+  // calls).  The wave's march lane slots follow at the kernel's end: 64 x (max over the lanes of each), exact at bounces 1
+  uint32_t it_p, it_s;
 };
 
 }  // namespace vx

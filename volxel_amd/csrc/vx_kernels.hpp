@@ -124,10 +124,29 @@ VXD void add_counts(DevCounters* dc, uint32_t samples, uint32_t rays, uint32_t p
   }
 }
 
+// max over the 64 lanes of the wave, in every lane (whole waves, like wave_sum)
+VXD uint32_t wave_max_u32(uint32_t x) {
+  int v = (int)x;   // trip counts: far below 2^31
+  auto mx = [](int a, int b) { return a > b ? a : b; };
+  v = mx(v, __builtin_amdgcn_update_dpp(0, v, 0x111, 0xf, 0xf, false));
+  v = mx(v, __builtin_amdgcn_update_dpp(0, v, 0x112, 0xf, 0xf, false));
+  v = mx(v, __builtin_amdgcn_update_dpp(0, v, 0x114, 0xf, 0xf, false));
+  v = mx(v, __builtin_amdgcn_update_dpp(0, v, 0x118, 0xf, 0xf, false));
+  v = mx(v, __builtin_amdgcn_update_dpp(0, v, 0x142, 0xa, 0xf, false));
+  v = mx(v, __builtin_amdgcn_update_dpp(0, v, 0x143, 0xc, 0xf, false));
+  return (uint32_t)__builtin_amdgcn_readlane(v, 63);
+}
+
+// The path-traced modes also report their march lane slots (VxCounters.lane_slots / active_lane_slots): a wave runs each of its
+// march loops until its slowest lane is through, so with one primary and one shadow segment per pixel (bounces 1) the loops
+// take max(it_p) + max(it_s) trips of 64 lane slots, of which sum(it_p + it_s) do work; with more bounces the maxima of the
+// per-lane totals bound the trips from below (the utilisation from above).
 VXD void flush_counts(DevCounters* dc, const Counts& c, uint32_t pixels, uint32_t block = 0xffffffffu) {
   uint32_t s = wave_sum(c.samples), r = wave_sum(c.rays), k = wave_sum(c.skips),
            g = wave_sum(c.grads), px = wave_sum(pixels), t = wave_sum(c.tf);
-  add_counts(dc, s, r, px, k, g, 0u, block, 0u, 0u, t);
+  const uint32_t work = wave_sum(c.it_p + c.it_s);
+  const uint32_t slots = work ? 64u * (wave_max_u32(c.it_p) + wave_max_u32(c.it_s)) : 0u;
+  add_counts(dc, s, r, px, k, g, slots, block, 0u, 0u, t, work);
 }
 
 constexpr uint32_t TF_LDS_MAX = 2048;  // entries staged in LDS (32 KiB); longer LUTs stay in L1/L2

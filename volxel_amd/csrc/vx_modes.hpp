@@ -307,7 +307,15 @@ struct Frame {
     bool free_path = true;
     uint32_t n_paths = 0;
     float t = 0.0f, f_p = 0.0f;
-    while (sample_volume<MODE>(ray, t, thr, s)) {
+    // trips of the march loops (Counts::it_p / it_s): DDA steps in the default mode, samples in the others
+    auto trips = [&]() { return MODE == VX_MODE_DEFAULT ? c.skips : c.samples; };
+    auto primary = [&]() {
+      const uint32_t before = trips();
+      const bool hit = sample_volume<MODE>(ray, t, thr, s);
+      c.it_p += trips() - before;
+      return hit;
+    };
+    while (primary()) {
       ray.o = madd3(ray.o, t, ray.d);
       float e0 = rng(s), e1 = rng(s);  // rng2 argument of sample_environment, fragment.frag:92
       V3 w_i = v3(-p.light_dir[0], -p.light_dir[1], -p.light_dir[2]);
@@ -317,7 +325,9 @@ struct Frame {
       if (pdf > 0.0f) {
         f_p = phase_hg(dot3(neg3(ray.d), w_i), p.volume_phase_g);
         float mis = p.show_environment > 0 ? power_heuristic(pdf, f_p) : 1.0f;
+        const uint32_t before = trips();
         float Tr = transmittance<MODE>(Ray{ray.o, w_i}, s);
+        c.it_s += trips() - before;
         L.x += thr.x * mis * f_p * Tr * Le.x / pdf;
         L.y += thr.y * mis * f_p * Tr * Le.y / pdf;
         L.z += thr.z * mis * f_p * Tr * Le.z / pdf;
