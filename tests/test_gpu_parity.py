@@ -1331,7 +1331,8 @@ def test_running_mean_in_the_render_kernel_is_bit_identical(oracle, monkeypatch,
     tf, L = benchmark_tf()
     res = {}
     monkeypatch.setenv("VX_DVR_WG", "0")     # (the shared-window kernel keeps the blend kernel: not what is under test here)
-    for key, fuse, fpl in (("serial", "1", 1), ("merge32", "0", 32), ("fused32", "1", 32), ("fused64", "1", 64)):
+    for key, fuse, fpl in (("serial", "1", 1), ("merge32", "0", 32), ("fused32", "1", 32), ("fused64", "1", 64), ("fused8", "1", 8),
+                           ("fused16", "1", 16)):
         monkeypatch.setenv("VX_DVR_FUSE", fuse)
         r = Volxel3DRenderer(203, 131)
         r.setup_from_grid(g)
@@ -1348,7 +1349,7 @@ def test_running_mean_in_the_render_kernel_is_bit_identical(oracle, monkeypatch,
         r.close()
     assert res["merge32"][3] > 0.0 and res["merge32"][4] == 32          # the blend kernel ran there ...
     assert res["fused64"][4] == 64
-    for key in ("merge32", "fused32", "fused64"):
+    for key in ("merge32", "fused32", "fused64", "fused8", "fused16"):
         assert np.array_equal(res[key][0], res["serial"][0]) and res[key][1:3] == res["serial"][1:3], key
     # ... and only for the partial launch here (7 frames): a fraction of the time
     assert 0.0 < res["fused32"][3] < 0.5 * res["merge32"][3]

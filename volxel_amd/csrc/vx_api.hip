@@ -1448,9 +1448,9 @@ int vx_render_frames(VxContext* c, uint32_t first_frame, uint32_t count, const f
         ma.weight[i] = weights[done + i];
       }
       // the LDS-window kernel applies the running mean itself when one wave holds every frame of its pixels: a launch of
-      // exactly 32 or 64 frames (MultiOut::fuse; VX_DVR_FUSE=0 keeps the result slabs and the blend kernel)
+      // exactly 8, 16, 32 or 64 frames (MultiOut::fuse; VX_DVR_FUSE=0 keeps the result slabs and the blend kernel)
       const bool fused = c->dvr_fuse &&
-                         ((tuned_lds && !c->dvr_shared_window && (n == 32u || n == 64u)) ||
+                         ((tuned_lds && !c->dvr_shared_window && (n == 8u || n == 16u || n == 32u || n == 64u)) ||
                           (!is_tuned(c) && n == 32u && generic_fusable(c, mo)));
       if (fused) {
         bool zero = false;

@@ -784,7 +784,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(PHONG ? (SK
     // have written to the frame's result slab (fma(1, L, 0 * 0)).
     V3 L = v3(0.f, 0.f, 0.f);
     if (in_image) L = dvr_radiance(p, v, r, Cx, Cy, Cz, T);
-    fold_frames(tile, lane, L, in_image, si, mo.accum, fuse, mo.count == 64u ? 6u : 5u);
+    fold_frames(tile, lane, L, in_image, si, mo.accum, fuse, 31u - (uint32_t)__builtin_clz(mo.count));   // count = 8, 16, 32 or 64
   } else if (in_image) dvr_store(p, v, r, Cx, Cy, Cz, T, weight, slab, si);
   const uint32_t n_px = (uint32_t)__builtin_popcountll(ballot(in_image));
   add_counts(dc, n_samples, n_rays, n_px, n_skipped, n_grads, n_slots, blk, n_loads, n_reads, n_tf);

@@ -162,8 +162,8 @@ struct MultiOut {
   uint32_t frame[MERGE_MAX];
   uint32_t count;
   // Round 4, behind the fields lane_frame_slot addresses (their offsets do not move): the running mean applied IN the render
-  // kernel.  fuse != 0 (the launcher sets it for a launch of exactly 32 or 64 frames of the LDS-window DVR kernel): a wave
-  // holds every frame of its 2 (or 1) pixels, so it folds their results in frame order into `accum` itself -- fragment.frag:158
+  // kernel.  fuse != 0 (the launcher sets it for a launch of exactly 8, 16, 32 or 64 frames of the LDS-window DVR kernel, of 32
+  // frames of render_generic): a wave holds every frame of its 8, 4, 2 (or 1) pixels, so it folds their results in frame order into `accum` itself -- fragment.frag:158
   // with weight[k] for frame slot k, exactly what merge_results does -- and neither the per-frame result slabs nor the blend
   // kernel are touched.  fuse == 2: some weight of the launch is 0 (the previous value is then dropped: merge_results'
   // `w != 0 ? acc : 0`), the fold tests each weight; fuse == 1: none is.
@@ -224,7 +224,7 @@ VXD float4* lane_frame_slot(uint32_t my_fslot, uint32_t& frame) {
 }
 
 // MultiOut::fuse: the running mean of a launch's frames applied by the wave that holds every frame of its pixels (lane l =
-// frame slot l >> psh of pixel l & (npx - 1); sh = 5: 2 pixels x 32 frames, sh = 6: 1 pixel x 64 frames).  The wave parks its
+// frame slot l >> psh of pixel l & (npx - 1); sh = 3 .. 6: 8 pixels x 8 frames .. 1 pixel x 64 frames).  The wave parks its
 // 64 results and the launch's weights {w, 1 - w} in `fold` (320 floats of wave-private LDS), then lanes 0 .. 3 npx - 1 each
 // fold one colour channel of one pixel through the frame slots in order: acc = fma(1 - w, r, w * (w != 0 ? acc : 0)) --
 // merge_results, operation for operation, on the value the unfused path writes to the frame's result slab
@@ -249,10 +249,11 @@ VXD void fold_frames(float* fold, uint32_t lane, V3 L, bool in_image, uint32_t s
   __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
   const unsigned long long inimg = ballot(in_image);
   const uint32_t fp = lane / 3u, ch = lane - 3u * fp;                     // pixel and channel this lane folds
-  const uint32_t si_p = (uint32_t)__builtin_amdgcn_readlane((int)si, 0), si_q = (uint32_t)__builtin_amdgcn_readlane((int)si, 1);
+  // the accumulator slot of pixel fp: hardware lane fp holds frame slot 0 of that pixel (fp < npx <= 8)
+  const uint32_t si_f = (uint32_t)__builtin_amdgcn_ds_bpermute((int)((fp & 7u) << 2), (int)si);
   const bool folds = lane < 3u * npx && ((inimg >> fp) & 1ull);
   if (folds) {
-    float* const px4 = reinterpret_cast<float*>(accum + (fp == 0u ? si_p : si_q));
+    float* const px4 = reinterpret_cast<float*>(accum + si_f);
     float acc = px4[ch];
     const float* rp = fold + fp * 3u + ch;
     if (fuse == 1u) {
