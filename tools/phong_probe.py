@@ -11,7 +11,7 @@ if len(sys.argv) > 1:
     r.set_layout(int(sys.argv[1]))
 for mode in ("dvr", "dvr_phong"):
     for jitter in (True,):
-        for P in (1, 16):
+        for P in (1, 32):
             r.settings.render_mode = mode
             r.settings.dvr_jitter = jitter
             r.restart_rendering(); r.bind_uniforms()
